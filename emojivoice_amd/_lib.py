@@ -1,0 +1,256 @@
+"""ctypes binding of ``libemojivoice_hip.so`` (C ABI declared in include/emojivoice.h).
+
+There is NO CPU fallback: importing works everywhere (so the package can be
+inspected on a CPU box) but any compute call raises ``EvLibraryError`` when the
+HIP library is missing or no GPU is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libemojivoice_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+EXPORTS = [
+    "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder",
+    "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read",
+    "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention",
+]
+
+
+class EvLibraryError(RuntimeError):
+    pass
+
+
+class ev_tensor_index(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("offset", C.c_uint64), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class ev_model_dims(C.Structure):
+    _fields_ = [("n_feats", C.c_int32), ("spk_emb_dim", C.c_int32), ("channels", C.c_int32), ("heads", C.c_int32),
+                ("head_dim", C.c_int32)]
+
+
+def build_library(force: bool = False, verbose: bool = False) -> str:
+    """Compile the HIP sources for gfx950 into emojivoice_amd/lib/ (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(CSRC, "ev_engine.hip")
+    deps = [src, os.path.join(CSRC, "ev_kernels.h"), os.path.join(os.path.dirname(_HERE), "include", "emojivoice.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", src, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen the library and declare every prototype.  Does not touch the GPU."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EvLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the EmojiVoice hot path)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, f32, u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    lib.ev_abi_version.restype = C.c_int
+    lib.ev_create.argtypes = [C.POINTER(vp), i32, C.POINTER(ev_model_dims)]
+    lib.ev_destroy.argtypes = [vp]
+    lib.ev_destroy.restype = None
+    lib.ev_last_error.argtypes = [vp]
+    lib.ev_last_error.restype = C.c_char_p
+    for f in (lib.ev_load_estimator, lib.ev_load_vocoder):
+        f.argtypes = [vp, vp, C.POINTER(ev_tensor_index), u64]
+    lib.ev_workspace_bytes.argtypes = [vp, i32, i32, i32]
+    lib.ev_workspace_bytes.restype = u64
+    lib.ev_cfm_decode.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp]
+    lib.ev_estimator.argtypes = [vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]
+    lib.ev_hifigan.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.ev_profile_enable.argtypes = [vp, i32]
+    lib.ev_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+    lib.ev_op_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
+    lib.ev_op_groupnorm_mish.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.ev_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.ev_op_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    for n in EXPORTS:
+        getattr(lib, n)  # raises AttributeError if a declared symbol is not exported
+    _lib = lib
+    return lib
+
+
+def _stream_ptr() -> int:
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One ``ev_handle`` on one GPU.  Tensors are torch CUDA tensors (fp32, contiguous)."""
+
+    def __init__(self, device: int = 0, spk_emb_dim: int = 64, heads: int = 2):
+        if not torch.cuda.is_available():
+            raise EvLibraryError("no ROCm GPU visible: the EmojiVoice hot path has no CPU fallback")
+        self.lib = load_library()
+        self.device = device
+        dims = ev_model_dims(80, spk_emb_dim, 256, heads, 64)
+        h = C.c_void_p()
+        rc = self.lib.ev_create(C.byref(h), device, C.byref(dims))
+        if rc != 0:
+            raise EvLibraryError(f"ev_create failed with code {rc}")
+        self.h = h
+        self.spk_emb_dim = spk_emb_dim
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.ev_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise EvLibraryError(f"{what} failed: {self.lib.ev_last_error(self.h).decode()}")
+
+    # ---- weights -----------------------------------------------------------
+    def _load(self, fn, tensors: Dict[str, torch.Tensor], what: str):
+        names = list(tensors.keys())
+        arrs = [np.ascontiguousarray(tensors[k].detach().to("cpu", torch.float32).numpy()).reshape(-1) for k in names]
+        blob = np.concatenate(arrs) if arrs else np.zeros(1, np.float32)
+        idx = (ev_tensor_index * len(names))()
+        off = 0
+        keep = []
+        for i, k in enumerate(names):
+            b = k.encode()
+            keep.append(b)
+            shp = tuple(tensors[k].shape)
+            idx[i].name = b
+            idx[i].offset = off
+            idx[i].ndim = len(shp)
+            for d, s in enumerate(shp):
+                idx[i].shape[d] = s
+            off += arrs[i].size
+        self._check(fn(self.h, blob.ctypes.data_as(C.c_void_p), idx, len(names)), what)
+
+    def load_estimator(self, tensors: Dict[str, torch.Tensor]):
+        """``tensors``: reference ``decoder.estimator.*`` entries with that prefix stripped, plus the derived
+        ``*.ff.net.0.alpha_exp`` / ``*.ff.net.0.beta_inv`` (see matcha_tts.estimator_tensors)."""
+        self._load(self.lib.ev_load_estimator, tensors, "ev_load_estimator")
+
+    def load_vocoder(self, tensors: Dict[str, torch.Tensor]):
+        self._load(self.lib.ev_load_vocoder, tensors, "ev_load_vocoder")
+
+    # ---- hot calls -----------------------------------------------------------
+    @staticmethod
+    def _f32(t: torch.Tensor) -> torch.Tensor:
+        assert t.is_cuda, "tensor must live on the GPU"
+        return t.contiguous().float()
+
+    def cfm_decode(self, mu, lengths, spk, z, n_steps: int, out_scale: float = 1.0, out_shift: float = 0.0):
+        mu, z = self._f32(mu), self._f32(z)
+        B, F, Tp = mu.shape
+        assert F == 80 and z.shape == mu.shape
+        lengths = lengths.to(mu.device, torch.int32).contiguous()
+        spk_p = None
+        if spk is not None:
+            spk = self._f32(spk)
+            spk_p = spk.data_ptr()
+        out = torch.empty_like(mu)
+        self._check(self.lib.ev_cfm_decode(self.h, mu.data_ptr(), lengths.data_ptr(), spk_p, z.data_ptr(), B, Tp, int(n_steps),
+                                           float(out_scale), float(out_shift), out.data_ptr(), _stream_ptr()), "ev_cfm_decode")
+        return out
+
+    def estimator(self, x, mu, lengths, spk, t: float):
+        x, mu = self._f32(x), self._f32(mu)
+        B, F, Tp = mu.shape
+        lengths = lengths.to(mu.device, torch.int32).contiguous()
+        spk_p = None
+        if spk is not None:
+            spk = self._f32(spk)
+            spk_p = spk.data_ptr()
+        out = torch.empty_like(mu)
+        self._check(self.lib.ev_estimator(self.h, x.data_ptr(), mu.data_ptr(), lengths.data_ptr(), spk_p, float(t), B, Tp,
+                                          out.data_ptr(), _stream_ptr()), "ev_estimator")
+        return out
+
+    def hifigan(self, mel):
+        mel = self._f32(mel)
+        B, F, T = mel.shape
+        assert F == 80
+        wav = torch.empty((B, 1, T * 256), dtype=torch.float32, device=mel.device)
+        self._check(self.lib.ev_hifigan(self.h, mel.data_ptr(), B, T, wav.data_ptr(), _stream_ptr()), "ev_hifigan")
+        return wav
+
+    def workspace_bytes(self, B: int, Tp: int, Tv: int) -> int:
+        return int(self.lib.ev_workspace_bytes(self.h, B, Tp, Tv))
+
+    # ---- profiling hooks (bench.py) -------------------------------------------
+    def profile_enable(self, on: bool):
+        self._check(self.lib.ev_profile_enable(self.h, int(on)), "ev_profile_enable")
+
+    def profile_read(self, reset: bool = True):
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.ev_profile_read(self.h, C.byref(ms), C.byref(fl), C.byref(n), int(reset)), "ev_profile_read")
+        return ms.value, fl.value, n.value
+
+    # ---- operator-level entry points (unit tests) ---------------------------------
+    def op_conv1d(self, x, w, bias, dilation=1, transposed=False, stride=1, padding=0, pre_lrelu_slope=-1.0):
+        x = self._f32(x)
+        B, Cin, T = x.shape
+        w = np.ascontiguousarray(w.detach().cpu().float().numpy())
+        if transposed:
+            Cout, K = w.shape[1], w.shape[2]
+            Tout = T * stride
+        else:
+            Cout, K = w.shape[0], w.shape[2]
+            Tout = T // stride
+        bp = None
+        if bias is not None:
+            bnp = np.ascontiguousarray(bias.detach().cpu().float().numpy())
+            bp = bnp.ctypes.data_as(C.c_void_p)
+        y = torch.empty((B, Cout, Tout), dtype=torch.float32, device=x.device)
+        self._check(self.lib.ev_op_conv1d(self.h, x.data_ptr(), w.ctypes.data_as(C.c_void_p), bp, B, Cin, T, Cout, K, dilation,
+                                          int(transposed), stride, padding, float(pre_lrelu_slope), y.data_ptr(), _stream_ptr()),
+                    "ev_op_conv1d")
+        return y
+
+    def op_groupnorm_mish(self, x, gamma, beta, lengths, groups=8):
+        x, gamma, beta = self._f32(x), self._f32(gamma), self._f32(beta)
+        B, Cc, T = x.shape
+        lengths = lengths.to(x.device, torch.int32).contiguous()
+        y = torch.empty_like(x)
+        self._check(self.lib.ev_op_groupnorm_mish(self.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), lengths.data_ptr(), B, Cc, T,
+                                                  groups, y.data_ptr(), _stream_ptr()), "ev_op_groupnorm_mish")
+        return y
+
+    def op_layernorm(self, x, gamma, beta):
+        x, gamma, beta = self._f32(x), self._f32(gamma), self._f32(beta)
+        rows, Cc = x.shape
+        y = torch.empty_like(x)
+        self._check(self.lib.ev_op_layernorm(self.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, Cc, y.data_ptr(),
+                                             _stream_ptr()), "ev_op_layernorm")
+        return y
+
+    def op_attention(self, qkv, lengths, heads=2):
+        qkv = self._f32(qkv)
+        B, T, _ = qkv.shape
+        lengths = lengths.to(qkv.device, torch.int32).contiguous()
+        out = torch.empty((B, T, heads * 64), dtype=torch.float32, device=qkv.device)
+        self._check(self.lib.ev_op_attention(self.h, qkv.data_ptr(), lengths.data_ptr(), B, T, heads, out.data_ptr(), _stream_ptr()),
+                    "ev_op_attention")
+        return out

@@ -1,0 +1,969 @@
+// Host engine + C ABI of the EmojiVoice hot path (see include/emojivoice.h).
+// Weight re-layout, workspace management and the launch sequence of the CFM
+// U-Net estimator (reference decoder.py:363-443) and the HiFi-GAN V1 generator
+// (reference hifigan/models.py:181-197) on the kernels of ev_kernels.h.
+#include "ev_kernels.h"
+#include "../../include/emojivoice.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+struct HostTensor {
+    const float* p = nullptr;
+    int ndim = 0;
+    int64_t shape[4] = {0, 0, 0, 0};
+    int64_t numel() const { int64_t n = 1; for (int i = 0; i < ndim; ++i) n *= shape[i]; return n; }
+};
+typedef std::unordered_map<std::string, HostTensor> TensorMap;
+
+struct Geom { int nrows, S, P, T; };  // flattened padded time axis of one resolution level
+
+// One convolution / linear layer packed for conv_gemm_kernel.
+struct ConvLayer {
+    float* W = nullptr;       // [ntaps][Mpad][Kpad]
+    float* bias = nullptr;    // [Cout] (stacked / phase-replicated as needed) or null
+    uint32_t* tapmask[3] = {nullptr, nullptr, nullptr};  // for BM = 128, 64, 32
+    bool sparse_taps = false;
+    int ntaps = 0, off[EV_MAX_TAPS] = {0};
+    int halo_lo = 0, halo_hi = 0;
+    int Cin = 0, Cout = 0, Mpad = 0, Kpad = 0;
+    double macs_per_row = 0;  // algorithmic MACs per output view-row (reference arithmetic, no padding)
+};
+
+struct Epi {
+    int act = ACT_NONE; float act_slope = 0.f; const float* act_a = nullptr; const float* act_b = nullptr;
+    int mask1 = 0; float scale = 1.f; const float* R = nullptr; int ldr = 0; int accum = 0; int div3 = 0;
+    int act2_lrelu = 0; float act2_slope = 0.f; int mask2 = 0; const float* rowmask = nullptr; int mmul = 1;
+    float* Y2 = nullptr; int ldy2 = 0;
+    float pro_slope = -1.f;                 // >= 0: prologue leaky-relu on the input
+    int isplit_log2 = 31, isstride = 0;     // input column split (pair view of a strided slice)
+    int osplit_log2 = 31, osstride = 0;     // output column split
+};
+
+struct ResnetW { ConvLayer c1, c2, res; float *g1, *b1, *g2, *b2; };
+struct TransW { ConvLayer qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln3g, *ln3b, *alpha, *binv; };
+
+struct EstimatorW {
+    bool loaded = false;
+    int in_ch = 0;  // 224 (or 160 single-speaker)
+    ConvLayer t1, t2, tmlp;  // time MLP: linear_1 (+SiLU), linear_2 (+Mish), 6 stacked resnet mlps
+    ResnetW rn[6];           // down0, down1, mid0, mid1, up0, up1
+    TransW tr[6];
+    ConvLayer down0, down1, up0, up1, fin_conv, fin_proj;
+    float *fin_g, *fin_b;
+};
+
+struct VocoderW {
+    bool loaded = false;
+    ConvLayer pre, post, ups[4];
+    ConvLayer c1[12][3], c2[12][3];
+    int ch[5];  // channels per level: 512, 256, 128, 64, 32
+};
+
+}  // namespace
+
+struct ev_handle {
+    int device = 0;
+    ev_model_dims dims;
+    std::string err;
+    std::vector<void*> owned;   // device allocations of the weights
+    EstimatorW est;
+    VocoderW voc;
+    // workspace
+    char* ws = nullptr; size_t ws_bytes = 0; size_t ws_used = 0;
+    int ws_B = -1, ws_Tp = -1, ws_Tv = -1;
+    // profiling
+    bool prof = false;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    double prof_flops = 0; int64_t prof_launches = 0;
+    hipStream_t stream = nullptr;
+};
+
+namespace {
+
+int fail(ev_handle* h, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (h) h->err = buf;
+    return 1;
+}
+#define HIPCHK(h, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(h, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+template <typename T>
+int dev_upload(ev_handle* h, const std::vector<T>& v, T** out) {
+    void* d = nullptr;
+    HIPCHK(h, hipMalloc(&d, v.size() * sizeof(T) + 16));
+    HIPCHK(h, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    h->owned.push_back(d);
+    *out = (T*)d;
+    return 0;
+}
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// finalize a layer whose packed host weights Wh [ntaps][Mpad][Kpad] and bias are given
+int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const std::vector<float>* bias) {
+    int lo = 0, hi = 0;
+    for (int i = 0; i < L.ntaps; ++i) { if (-L.off[i] > lo) lo = -L.off[i]; if (L.off[i] > hi) hi = L.off[i]; }
+    L.halo_lo = lo; L.halo_hi = hi;
+    if (lo + hi > EV_HALO) return fail(h, "conv halo %d exceeds EV_HALO", lo + hi);
+    if (dev_upload(h, Wh, &L.W)) return 1;
+    if (bias) { if (dev_upload(h, *bias, &L.bias)) return 1; }
+    // per-tile non-zero tap masks
+    const int bms[3] = {128, 64, 32};
+    L.sparse_taps = false;
+    for (int k = 0; k < 3; ++k) {
+        const int BM = bms[k];
+        const int mt = L.Mpad / BM;
+        std::vector<uint32_t> mask(mt, 0u);
+        for (int t = 0; t < mt; ++t)
+            for (int tap = 0; tap < L.ntaps; ++tap) {
+                bool nz = false;
+                for (int m = t * BM; m < (t + 1) * BM && !nz; ++m) {
+                    const float* row = &Wh[((size_t)tap * L.Mpad + m) * L.Kpad];
+                    for (int c = 0; c < L.Kpad; ++c) if (row[c] != 0.f) { nz = true; break; }
+                }
+                if (nz) mask[t] |= 1u << tap;
+                else if (t * BM < L.Cout) L.sparse_taps = true;
+            }
+        if (dev_upload(h, mask, &L.tapmask[k])) return 1;
+    }
+    return 0;
+}
+
+// Conv1d weight (Cout, Cin, K), stride 1, "same" padding (K*d - d)/2, dilation d
+int pack_conv(ev_handle* h, ConvLayer& L, const HostTensor& w, const HostTensor* b, int dilation) {
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], K = w.ndim == 3 ? (int)w.shape[2] : 1;
+    if (K > EV_MAX_TAPS) return fail(h, "kernel size %d > %d", K, EV_MAX_TAPS);
+    L.Cin = Cin; L.Cout = Cout; L.ntaps = K; L.Mpad = round_up(Cout, 128); L.Kpad = round_up(Cin, EV_BK);
+    const int pad = (K * dilation - dilation) / 2;
+    for (int k = 0; k < K; ++k) L.off[k] = k * dilation - pad;
+    std::vector<float> Wh((size_t)K * L.Mpad * L.Kpad, 0.f);
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int k = 0; k < K; ++k) Wh[((size_t)k * L.Mpad + co) * L.Kpad + ci] = w.p[((size_t)co * Cin + ci) * K + k];
+    L.macs_per_row = (double)Cout * Cin * K;
+    std::vector<float> bh;
+    if (b) bh.assign(b->p, b->p + Cout);
+    return finish_layer(h, L, Wh, b ? &bh : nullptr);
+}
+
+// Several (Cout_i, Cin) linears sharing one input stacked along the output axis
+int pack_linear_stack(ev_handle* h, ConvLayer& L, const std::vector<const HostTensor*>& ws, const std::vector<const HostTensor*>& bs) {
+    const int Cin = (int)ws[0]->shape[1];
+    int Cout = 0;
+    for (auto* w : ws) Cout += (int)w->shape[0];
+    L.Cin = Cin; L.Cout = Cout; L.ntaps = 1; L.off[0] = 0; L.Mpad = round_up(Cout, 128); L.Kpad = round_up(Cin, EV_BK);
+    std::vector<float> Wh((size_t)L.Mpad * L.Kpad, 0.f), bh((size_t)Cout, 0.f);
+    int r0 = 0;
+    for (size_t i = 0; i < ws.size(); ++i) {
+        const int co_n = (int)ws[i]->shape[0];
+        for (int co = 0; co < co_n; ++co) {
+            for (int ci = 0; ci < Cin; ++ci) Wh[(size_t)(r0 + co) * L.Kpad + ci] = ws[i]->p[(size_t)co * Cin + ci];
+            if (!bs.empty() && bs[i]) bh[r0 + co] = bs[i]->p[co];
+        }
+        r0 += co_n;
+    }
+    L.macs_per_row = (double)Cout * Cin;
+    return finish_layer(h, L, Wh, bs.empty() ? nullptr : &bh);
+}
+
+// ConvTranspose1d weight (Cin, Cout, K), stride s, padding p as a polyphase conv over INPUT frames:
+// view-row q holds the s output frames s*q .. s*q+s-1, column r*Cout + co;
+//   out[s*q + r][co] = sum_{k == (r+p) mod s} W[ci][co][k] * x[q + (r + p - k)/s][ci]
+int pack_convT(ev_handle* h, ConvLayer& L, const HostTensor& w, const HostTensor* b, int s, int p) {
+    const int Cin = (int)w.shape[0], Cout = (int)w.shape[1], K = (int)w.shape[2];
+    std::vector<int> offs;
+    for (int r = 0; r < s; ++r)
+        for (int k = 0; k < K; ++k)
+            if ((r + p - k) % s == 0) {
+                int o = (r + p - k) / s;
+                bool found = false;
+                for (int x : offs) if (x == o) found = true;
+                if (!found) offs.push_back(o);
+            }
+    for (size_t i = 0; i < offs.size(); ++i) for (size_t j = i + 1; j < offs.size(); ++j) if (offs[j] < offs[i]) std::swap(offs[i], offs[j]);
+    if ((int)offs.size() > EV_MAX_TAPS) return fail(h, "too many polyphase taps");
+    L.Cin = Cin; L.Cout = s * Cout; L.ntaps = (int)offs.size(); L.Mpad = round_up(L.Cout, 128); L.Kpad = round_up(Cin, EV_BK);
+    for (int i = 0; i < L.ntaps; ++i) L.off[i] = offs[i];
+    std::vector<float> Wh((size_t)L.ntaps * L.Mpad * L.Kpad, 0.f), bh((size_t)L.Cout, 0.f);
+    for (int r = 0; r < s; ++r)
+        for (int k = 0; k < K; ++k) {
+            if ((r + p - k) % s != 0) continue;
+            const int o = (r + p - k) / s;
+            int ti = 0;
+            while (offs[ti] != o) ++ti;
+            for (int co = 0; co < Cout; ++co)
+                for (int ci = 0; ci < Cin; ++ci)
+                    Wh[((size_t)ti * L.Mpad + r * Cout + co) * L.Kpad + ci] = w.p[((size_t)ci * Cout + co) * K + k];
+        }
+    if (b) for (int r = 0; r < s; ++r) for (int co = 0; co < Cout; ++co) bh[r * Cout + co] = b->p[co];
+    L.macs_per_row = (double)Cin * Cout * K;  // per input frame: every (ci, co, k) product happens exactly once
+    return finish_layer(h, L, Wh, b ? &bh : nullptr);
+}
+
+// Conv1d (Cout, Cin, 3) stride 2 padding 1 over the PAIR view of its input (row t' = frames 2t', 2t'+1; 2*Cin columns):
+//   out[t'] = W0 x[2t'-1] + W1 x[2t'] + W2 x[2t'+1]
+int pack_conv_stride2(ev_handle* h, ConvLayer& L, const HostTensor& w, const HostTensor* b) {
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], K = (int)w.shape[2];
+    if (K != 3) return fail(h, "stride-2 conv expects k=3");
+    L.Cin = 2 * Cin; L.Cout = Cout; L.ntaps = 2; L.off[0] = -1; L.off[1] = 0; L.Mpad = round_up(Cout, 128); L.Kpad = round_up(2 * Cin, EV_BK);
+    std::vector<float> Wh((size_t)2 * L.Mpad * L.Kpad, 0.f), bh;
+    for (int co = 0; co < Cout; ++co)
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* wk = &w.p[((size_t)co * Cin + ci) * 3];
+            Wh[((size_t)0 * L.Mpad + co) * L.Kpad + Cin + ci] = wk[0];  // frame 2t'-1 = second half of pair t'-1
+            Wh[((size_t)1 * L.Mpad + co) * L.Kpad + ci] = wk[1];        // frame 2t'
+            Wh[((size_t)1 * L.Mpad + co) * L.Kpad + Cin + ci] = wk[2];  // frame 2t'+1
+        }
+    if (b) bh.assign(b->p, b->p + Cout);
+    L.macs_per_row = (double)Cout * Cin * 3;
+    return finish_layer(h, L, Wh, b ? &bh : nullptr);
+}
+
+const HostTensor* find(ev_handle* h, const TensorMap& m, const std::string& k) {
+    auto it = m.find(k);
+    if (it == m.end()) { fail(h, "missing tensor '%s'", k.c_str()); return nullptr; }
+    return &it->second;
+}
+
+int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** out) {
+    const HostTensor* t = find(h, m, k);
+    if (!t) return 1;
+    std::vector<float> v(t->p, t->p + t->numel());
+    return dev_upload(h, v, out);
+}
+
+// ---------------------------------------------------------------------------
+// launching
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+void launch_cfg(const ConvParams& p, hipStream_t st) {
+    const size_t smem = (size_t)((BN + EV_HALO) * EV_LDK + EV_WROWS * EV_LDK) * sizeof(float);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+}
+
+int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {
+    ConvParams p;
+    memset(&p, 0, sizeof p);
+    p.X = X; p.ldx = ldx; p.Cin = L.Cin; p.isplit_log2 = e.isplit_log2; p.isstride = e.isstride;
+    p.W = L.W; p.Mpad = L.Mpad; p.Kpad = L.Kpad; p.bias = L.bias;
+    p.Y = Y; p.ldy = ldy; p.Cout = L.Cout; p.osplit_log2 = e.osplit_log2; p.osstride = e.osstride; p.mmul = e.mmul;
+    p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T;
+    p.ntaps = L.ntaps; for (int i = 0; i < L.ntaps; ++i) p.off[i] = L.off[i];
+    p.halo_lo = L.halo_lo; p.halo_hi = L.halo_hi;
+    p.pro_lrelu = e.pro_slope >= 0.f; p.pro_slope = e.pro_slope;
+    p.act = e.act; p.act_slope = e.act_slope; p.act_a = e.act_a; p.act_b = e.act_b;
+    p.mask1 = e.mask1; p.scale = e.scale; p.R = e.R; p.ldr = e.ldr; p.accum = e.accum; p.div3 = e.div3;
+    p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope; p.mask2 = e.mask2; p.rowmask = e.rowmask;
+    p.Y2 = e.Y2; p.ldy2 = e.ldy2;
+    if ((ldx & 3) || (L.Cin & 3)) return fail(h, "conv input must be float4-aligned (ldx %d Cin %d)", ldx, L.Cin);
+
+    // tile choice: BM by output width; fall back to smaller tiles when the grid would not fill 256 CUs twice
+    int cfg;
+    if (L.Cout <= 32) cfg = 2;
+    else if (L.Cout <= 64) cfg = 1;
+    else {
+        const long wgs128 = (long)(L.Mpad / 128) * ((g.nrows + 127) / 128);
+        cfg = (wgs128 >= 512 || L.Cout % 128 != 0) ? 0 : 1;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t ev; HIPCHK(h, hipEventCreate(&ev)); h->ev_pool.push_back(ev); }
+        }
+        e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+    }
+    if (cfg == 0) {
+        p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.tapmask = L.sparse_taps ? L.tapmask[0] : nullptr;
+        launch_cfg<128, 128, 2, 2>(p, h->stream);
+    } else if (cfg == 1) {
+        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.tapmask = L.sparse_taps ? L.tapmask[1] : nullptr;
+        launch_cfg<64, 128, 2, 2>(p, h->stream);
+    } else {
+        p.mtiles = (L.Cout + 31) / 32; p.ntiles = (g.nrows + 255) / 256; p.tapmask = L.sparse_taps ? L.tapmask[2] : nullptr;
+        launch_cfg<32, 256, 1, 4>(p, h->stream);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (h->prof) {
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        const double valid_rows = (double)(g.nrows / g.S) * g.T;
+        h->prof_flops += 2.0 * L.macs_per_row * valid_rows;
+        h->prof_launches += 1;
+    }
+    return 0;
+}
+
+int launch_gn(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const float* gamma, const float* beta, const float* rowmask,
+              const float* temb, const float* R, int ldr, const Geom& g, int C, int mode) {
+    GNParams p;
+    p.X = X; p.ldx = ldx; p.Y = Y; p.ldy = ldy; p.gamma = gamma; p.beta = beta; p.rowmask = rowmask; p.temb = temb; p.R = R; p.ldr = ldr;
+    p.S = g.S; p.P = g.P; p.T = g.T; p.CG = C / 8; p.mode = mode; p.eps = 1e-5f;
+    if (p.CG != 32) return fail(h, "groupnorm kernel expects 32 channels per group, got %d", p.CG);
+    hipLaunchKernelGGL(groupnorm_mish_kernel, dim3(g.nrows / g.S, 8), dim3(256), 0, h->stream, p);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int launch_ln(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const float* gamma, const float* beta, const Geom& g) {
+    LNParams p;
+    p.X = X; p.ldx = ldx; p.Y = Y; p.ldy = ldy; p.gamma = gamma; p.beta = beta; p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T; p.eps = 1e-5f;
+    hipLaunchKernelGGL(layernorm256_kernel, dim3((g.nrows + 3) / 4), dim3(256), 0, h->stream, p);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int launch_attn(ev_handle* h, const float* QKV, int ld, float* O, int ldo, const float* rowmask, const Geom& g, int H) {
+    AttnParams p;
+    p.QKV = QKV; p.ld = ld; p.O = O; p.ldo = ldo; p.rowmask = rowmask; p.S = g.S; p.P = g.P; p.T = g.T; p.H = H; p.scale = 0.125f;
+    hipLaunchKernelGGL(attention_kernel, dim3((g.T + 127) / 128, H, g.nrows / g.S), dim3(256), 0, h->stream, p);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// workspace: bump allocator over one arena, zeroed when the shape changes
+// ---------------------------------------------------------------------------
+struct Bump {
+    char* base; size_t off = 0; size_t cap;
+    float* take(size_t nfloats) {
+        size_t bytes = (nfloats * sizeof(float) + 255) & ~(size_t)255;
+        float* p = (float*)(base ? base + off : nullptr);
+        off += bytes;
+        return p;
+    }
+};
+
+struct EstBufs {
+    Geom g0, g1, gt;  // level 0 (T), level 1 (T/2), time grid
+    float *rm0, *rm1, *X0, *state, *A0, *B0, *R0, *H0, *LN0, *QKV0, *ATT0, *FF0, *CAT1, *U1, *F0, *G0, *V0;
+    float *A1, *B1, *R1, *H1, *LN1, *QKV1, *ATT1, *FF1, *CAT0, *D1, *D2, *M1, *UU;
+    float *tv, *temb_in, *temb_a, *temb_b, *tproj;
+};
+
+void plan_est(Bump& b, int B, int Tp, int in_ch, int nsteps, EstBufs& e) {
+    e.g0 = {B * (Tp + 4), Tp + 4, 2, Tp};
+    e.g1 = {B * (Tp / 2 + 2), Tp / 2 + 2, 1, Tp / 2};
+    e.gt = {nsteps, nsteps, 0, nsteps};
+    const size_t n0 = e.g0.nrows, n1 = e.g1.nrows;
+    e.rm0 = b.take(n0); e.rm1 = b.take(n1);
+    e.X0 = b.take(n0 * in_ch); e.state = b.take(n0 * 80);
+    e.A0 = b.take(n0 * 256); e.B0 = b.take(n0 * 256); e.R0 = b.take(n0 * 256); e.H0 = b.take(n0 * 256); e.LN0 = b.take(n0 * 256);
+    e.QKV0 = b.take(n0 * 384); e.ATT0 = b.take(n0 * 128); e.FF0 = b.take(n0 * 1024); e.CAT1 = b.take(n0 * 512);
+    e.U1 = b.take(n0 * 256); e.F0 = b.take(n0 * 256); e.G0 = b.take(n0 * 256); e.V0 = b.take(n0 * 80);
+    e.A1 = b.take(n1 * 256); e.B1 = b.take(n1 * 256); e.R1 = b.take(n1 * 256); e.H1 = b.take(n1 * 256); e.LN1 = b.take(n1 * 256);
+    e.QKV1 = b.take(n1 * 384); e.ATT1 = b.take(n1 * 128); e.FF1 = b.take(n1 * 1024); e.CAT0 = b.take(n1 * 512);
+    e.D1 = b.take(n1 * 256); e.D2 = b.take(n1 * 256); e.M1 = b.take(n1 * 256); e.UU = b.take(n1 * 256);
+    const size_t ns = nsteps;
+    e.tv = b.take(ns); e.temb_in = b.take(ns * in_ch); e.temb_a = b.take(ns * 1024); e.temb_b = b.take(ns * 1024); e.tproj = b.take(ns * 1536);
+}
+
+struct VocBufs {
+    Geom g[5];
+    float *M0, *C0;
+    float *U[5], *XS[5], *T1[5], *Pa[5], *Pb[5];
+};
+
+void plan_voc(Bump& b, int B, int T, const int* ch, VocBufs& v) {
+    const int rates[4] = {8, 8, 2, 2};
+    int Tl = T, Pl = 4;
+    v.g[0] = {B * (Tl + 2 * Pl), Tl + 2 * Pl, Pl, Tl};
+    for (int l = 1; l <= 4; ++l) {
+        Tl *= rates[l - 1]; Pl *= rates[l - 1];
+        v.g[l] = {B * (Tl + 2 * Pl), Tl + 2 * Pl, Pl, Tl};
+    }
+    v.M0 = b.take((size_t)v.g[0].nrows * 80);
+    v.C0 = b.take((size_t)v.g[0].nrows * ch[0]);
+    for (int l = 1; l <= 4; ++l) {
+        const size_t n = (size_t)v.g[l].nrows * ch[l];
+        v.U[l] = b.take(n); v.XS[l] = b.take(n); v.T1[l] = b.take(n); v.Pa[l] = b.take(n); v.Pb[l] = b.take(n);
+    }
+}
+
+constexpr int MAX_STEPS_PLAN = 64;  // time-grid buffers are planned for up to this many Euler steps
+
+size_t plan_all(ev_handle* h, char* base, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
+    Bump b{base, 0, 0};
+    EstBufs e; VocBufs v;
+    if (Tp > 0) plan_est(b, B, Tp, h->est.loaded ? h->est.in_ch : 2 * h->dims.n_feats + h->dims.spk_emb_dim, MAX_STEPS_PLAN, e);
+    if (Tv > 0) {
+        int ch[5] = {512, 256, 128, 64, 32};
+        plan_voc(b, B, Tv, h->voc.loaded ? h->voc.ch : ch, v);
+    }
+    if (eb) *eb = e;
+    if (vb) *vb = v;
+    return b.off;
+}
+
+// make sure the arena fits (B, Tp, Tv); zero it when the geometry changes (pad rows must be zero)
+int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
+    // keep the other path's last shape so alternating cfm/hifigan calls do not thrash
+    if (Tp <= 0) Tp = h->ws_Tp > 0 && h->ws_B == B ? h->ws_Tp : 0;
+    if (Tv <= 0) Tv = h->ws_Tv > 0 && h->ws_B == B ? h->ws_Tv : 0;
+    const size_t need = plan_all(h, nullptr, B, Tp, Tv, nullptr, nullptr);
+    bool rezero = (B != h->ws_B || Tp != h->ws_Tp || Tv != h->ws_Tv);
+    if (need > h->ws_bytes) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (h->ws) HIPCHK(h, hipFree(h->ws));
+        h->ws = nullptr; h->ws_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&h->ws, need));
+        h->ws_bytes = need;
+        rezero = true;
+    }
+    if (rezero) {
+        HIPCHK(h, hipMemsetAsync(h->ws, 0, need, h->stream));
+        h->ws_B = B; h->ws_Tp = Tp; h->ws_Tv = Tv;
+    }
+    plan_all(h, h->ws, B, Tp, Tv, eb, vb);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// estimator forward (decoder.py:363-443).  On entry X0 holds [x*m | mu*m | spk*m].
+// ---------------------------------------------------------------------------
+struct LevelBufs { float *A, *Bf, *R, *H, *LN, *QKV, *ATT, *FF; const float* rm; Geom g; };
+
+int run_resnet(ev_handle* h, const ResnetW& w, const float* X, int ldx, const LevelBufs& L, const float* temb) {
+    Epi e;
+    if (launch_conv(h, w.c1, X, ldx, L.A, 256, L.g, e)) return 1;
+    if (launch_gn(h, L.A, 256, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1)) return 1;
+    if (launch_conv(h, w.c2, L.Bf, 256, L.A, 256, L.g, e)) return 1;
+    if (launch_conv(h, w.res, X, ldx, L.R, 256, L.g, e)) return 1;
+    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.R, 256, L.g, 256, 2);
+}
+
+// BasicTransformerBlock (transformer.py:243-316) on L.H; result (masked) -> Z with row stride ldz
+int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z, int ldz, int heads) {
+    Epi e;
+    if (launch_ln(h, L.H, 256, L.LN, 256, w.ln1g, w.ln1b, L.g)) return 1;
+    if (launch_conv(h, w.qkv, L.LN, 256, L.QKV, 384, L.g, e)) return 1;
+    if (launch_attn(h, L.QKV, 384, L.ATT, 128, L.rm, L.g, heads)) return 1;
+    Epi eo; eo.R = L.H; eo.ldr = 256;
+    if (launch_conv(h, w.out, L.ATT, 128, L.H, 256, L.g, eo)) return 1;  // H <- attn + H (in place, element-wise aliasing only)
+    if (launch_ln(h, L.H, 256, L.LN, 256, w.ln3g, w.ln3b, L.g)) return 1;
+    Epi e1; e1.act = ACT_SNAKE; e1.act_a = w.alpha; e1.act_b = w.binv;
+    if (launch_conv(h, w.ff1, L.LN, 256, L.FF, 1024, L.g, e1)) return 1;
+    Epi e2; e2.R = L.H; e2.ldr = 256; e2.mask2 = 1; e2.rowmask = L.rm;
+    return launch_conv(h, w.ff2, L.FF, 1024, Z, ldz, L.g, e2);
+}
+
+// One estimator evaluation.  euler: state += dt * v, X0[:, :80] = state * m ; else V0 = v.
+int run_estimator(ev_handle* h, EstBufs& b, int step, float dt, bool euler) {
+    const EstimatorW& w = h->est;
+    const int heads = h->dims.heads;
+    LevelBufs L0{b.A0, b.B0, b.R0, b.H0, b.LN0, b.QKV0, b.ATT0, b.FF0, b.rm0, b.g0};
+    LevelBufs L1{b.A1, b.B1, b.R1, b.H1, b.LN1, b.QKV1, b.ATT1, b.FF1, b.rm1, b.g1};
+    const float* tp = b.tproj + (size_t)step * 1536;
+    // down 0 @T
+    if (run_resnet(h, w.rn[0], b.X0, w.in_ch, L0, tp + 0 * 256)) return 1;
+    if (run_transformer(h, w.tr[0], L0, b.CAT1 + 256, 512, heads)) return 1;      // hidden 0
+    {   // Downsample1D k3 s2 p1 over the pair view of CAT1[:, 256:512]
+        Epi e; e.isplit_log2 = 8; e.isstride = 512; e.mask1 = 1; e.rowmask = b.rm1;
+        if (launch_conv(h, w.down0, b.CAT1 + 256, 1024, b.D1, 256, b.g1, e)) return 1;
+    }
+    // down 1 @T/2
+    if (run_resnet(h, w.rn[1], b.D1, 256, L1, tp + 1 * 256)) return 1;
+    if (run_transformer(h, w.tr[1], L1, b.CAT0 + 256, 512, heads)) return 1;      // hidden 1
+    { Epi e; e.mask1 = 1; e.rowmask = b.rm1; if (launch_conv(h, w.down1, b.CAT0 + 256, 512, b.D2, 256, b.g1, e)) return 1; }
+    // mid
+    if (run_resnet(h, w.rn[2], b.D2, 256, L1, tp + 2 * 256)) return 1;
+    if (run_transformer(h, w.tr[2], L1, b.M1, 256, heads)) return 1;
+    if (run_resnet(h, w.rn[3], b.M1, 256, L1, tp + 3 * 256)) return 1;
+    if (run_transformer(h, w.tr[3], L1, b.CAT0, 512, heads)) return 1;
+    // up 0 @T/2: cat([x, hidden1])
+    if (run_resnet(h, w.rn[4], b.CAT0, 512, L1, tp + 4 * 256)) return 1;
+    if (run_transformer(h, w.tr[4], L1, b.UU, 256, heads)) return 1;
+    {   // ConvTranspose1d k4 s2 p1: view-row q -> frames 2q, 2q+1 of CAT1[:, 0:256]
+        Epi e; e.osplit_log2 = 8; e.osstride = 512; e.mask1 = 1; e.rowmask = b.rm0; e.mmul = 2;
+        if (launch_conv(h, w.up0, b.UU, 256, b.CAT1, 1024, b.g1, e)) return 1;
+    }
+    // up 1 @T: cat([x, hidden0])
+    if (run_resnet(h, w.rn[5], b.CAT1, 512, L0, tp + 5 * 256)) return 1;
+    if (run_transformer(h, w.tr[5], L0, b.U1, 256, heads)) return 1;
+    { Epi e; e.mask1 = 1; e.rowmask = b.rm0; if (launch_conv(h, w.up1, b.U1, 256, b.F0, 256, b.g0, e)) return 1; }
+    // final block + projection
+    { Epi e; if (launch_conv(h, w.fin_conv, b.F0, 256, b.A0, 256, b.g0, e)) return 1; }
+    if (launch_gn(h, b.A0, 256, b.G0, 256, w.fin_g, w.fin_b, b.rm0, nullptr, nullptr, 0, b.g0, 256, 0)) return 1;
+    if (euler) {
+        Epi e; e.mask1 = 1; e.rowmask = b.rm0; e.scale = dt; e.R = b.state; e.ldr = 80; e.Y2 = b.X0; e.ldy2 = w.in_ch;
+        return launch_conv(h, w.fin_proj, b.G0, 256, b.state, 80, b.g0, e);
+    }
+    Epi e; e.mask1 = 1; e.rowmask = b.rm0;
+    return launch_conv(h, w.fin_proj, b.G0, 256, b.V0, 80, b.g0, e);
+}
+
+// sinusoidal embedding + time MLP + the six resnet time projections for a list of times
+int run_time_mlp(ev_handle* h, EstBufs& b, const std::vector<float>& ts) {
+    const EstimatorW& w = h->est;
+    const int nt = (int)ts.size(), dim = w.in_ch, half = dim / 2;
+    std::vector<float> emb((size_t)nt * dim);
+    const float ne = -(float)(log(10000.0) / (double)(half - 1));   // decoder.py:24-25, evaluated in float like torch
+    for (int i = 0; i < nt; ++i) {
+        const float st = 1000.0f * ts[i];
+        for (int k = 0; k < half; ++k) {
+            const float f = expf((float)k * ne);
+            const float a = st * f;
+            emb[(size_t)i * dim + k] = sinf(a);
+            emb[(size_t)i * dim + half + k] = cosf(a);
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(b.temb_in, emb.data(), emb.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // emb is a stack-lifetime host buffer
+    Geom gt{nt, nt, 0, nt};
+    Epi e1; e1.act = ACT_SILU;
+    if (launch_conv(h, w.t1, b.temb_in, dim, b.temb_a, 1024, gt, e1)) return 1;
+    Epi e2; e2.act = ACT_MISH;   // every consumer applies Mish first (decoder.py:49)
+    if (launch_conv(h, w.t2, b.temb_a, 1024, b.temb_b, 1024, gt, e2)) return 1;
+    Epi e3;
+    return launch_conv(h, w.tmlp, b.temb_b, 1024, b.tproj, 1536, gt, e3);
+}
+
+int prep_inputs(ev_handle* h, EstBufs& b, const float* d_x, const float* d_mu, const int32_t* d_len, const float* d_spk, int B, int Tp) {
+    const EstimatorW& w = h->est;
+    hipStream_t st = h->stream;
+    hipLaunchKernelGGL(rowmask_kernel, dim3((b.g0.nrows + 255) / 256), dim3(256), 0, st, b.rm0, d_len, b.g0.nrows, b.g0.S, b.g0.P, b.g0.T, 1);
+    hipLaunchKernelGGL(rowmask_kernel, dim3((b.g1.nrows + 255) / 256), dim3(256), 0, st, b.rm1, d_len, b.g1.nrows, b.g1.S, b.g1.P, b.g1.T, 2);
+    dim3 grid((Tp + 31) / 32, (80 + 31) / 32, B);
+    // ODE state (unmasked) and the masked estimator input [x*m | mu*m | spk*m]
+    hipLaunchKernelGGL(cm_to_fm_kernel, grid, dim3(256), 0, st, d_x, b.state, 80, 0, 80, Tp, b.g0.S, b.g0.P, (const float*)nullptr, 1.0f);
+    hipLaunchKernelGGL(cm_to_fm_kernel, grid, dim3(256), 0, st, d_x, b.X0, w.in_ch, 0, 80, Tp, b.g0.S, b.g0.P, (const float*)b.rm0, 1.0f);
+    hipLaunchKernelGGL(cm_to_fm_kernel, grid, dim3(256), 0, st, d_mu, b.X0, w.in_ch, 80, 80, Tp, b.g0.S, b.g0.P, (const float*)b.rm0, 1.0f);
+    if (w.in_ch > 160) {
+        const int C = w.in_ch - 160;
+        const long tot = (long)b.g0.nrows * C;
+        hipLaunchKernelGGL(bcast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_spk, b.X0, w.in_ch, 160, C, b.g0.nrows, b.g0.S, b.g0.P, b.g0.T, (const float*)b.rm0);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int ev_abi_version(void) { return EV_ABI_VERSION; }
+
+int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
+    if (!out || !dims) return 1;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return 2;
+    if (hipSetDevice(device) != hipSuccess) return 3;
+    ev_handle* h = new ev_handle();
+    h->device = device;
+    h->dims = *dims;
+    if (dims->n_feats != 80 || dims->channels != 256 || dims->head_dim != 64 || dims->heads < 1 || dims->heads > 8) {
+        delete h;
+        return 4;
+    }
+    *out = h;
+    return 0;
+}
+
+void ev_destroy(ev_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (void* p : h->owned) hipFree(p);
+    if (h->ws) hipFree(h->ws);
+    for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    delete h;
+}
+
+const char* ev_last_error(ev_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+static int build_map(ev_handle* h, const float* blob, const ev_tensor_index* index, size_t n, TensorMap& m) {
+    if (!blob || !index) return fail(h, "null blob/index");
+    for (size_t i = 0; i < n; ++i) {
+        HostTensor t;
+        t.p = blob + index[i].offset;
+        t.ndim = index[i].ndim;
+        if (t.ndim < 0 || t.ndim > 4) return fail(h, "bad ndim for %s", index[i].name);
+        for (int d = 0; d < t.ndim; ++d) t.shape[d] = index[i].shape[d];
+        m[index[i].name] = t;
+    }
+    return 0;
+}
+
+int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* index, size_t n) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    TensorMap m;
+    if (build_map(h, blob, index, n, m)) return 1;
+    EstimatorW& w = h->est;
+    w.loaded = false;
+#define T_(k) find(h, m, k)
+#define REQ(x) do { if (x) return 1; } while (0)
+    const HostTensor* l1 = T_("time_mlp.linear_1.weight");
+    if (!l1) return 1;
+    w.in_ch = (int)l1->shape[1];
+    if (w.in_ch != 2 * h->dims.n_feats + h->dims.spk_emb_dim) return fail(h, "estimator in_channels %d != 2*n_feats + spk_emb_dim", w.in_ch);
+    {
+        const HostTensor *b1 = T_("time_mlp.linear_1.bias"), *l2 = T_("time_mlp.linear_2.weight"), *b2 = T_("time_mlp.linear_2.bias");
+        if (!b1 || !l2 || !b2) return 1;
+        REQ(pack_linear_stack(h, w.t1, {l1}, {b1}));
+        REQ(pack_linear_stack(h, w.t2, {l2}, {b2}));
+    }
+    const char* rn_names[6] = {"down_blocks.0.0", "down_blocks.1.0", "mid_blocks.0.0", "mid_blocks.1.0", "up_blocks.0.0", "up_blocks.1.0"};
+    const char* tr_names[6] = {"down_blocks.0.1.0", "down_blocks.1.1.0", "mid_blocks.0.1.0", "mid_blocks.1.1.0", "up_blocks.0.1.0", "up_blocks.1.1.0"};
+    std::vector<const HostTensor*> mw, mb;
+    for (int i = 0; i < 6; ++i) {
+        const std::string p = rn_names[i];
+        const HostTensor *c1w = T_(p + ".block1.block.0.weight"), *c1b = T_(p + ".block1.block.0.bias");
+        const HostTensor *c2w = T_(p + ".block2.block.0.weight"), *c2b = T_(p + ".block2.block.0.bias");
+        const HostTensor *rw = T_(p + ".res_conv.weight"), *rb = T_(p + ".res_conv.bias");
+        const HostTensor *tw = T_(p + ".mlp.1.weight"), *tb = T_(p + ".mlp.1.bias");
+        if (!c1w || !c1b || !c2w || !c2b || !rw || !rb || !tw || !tb) return 1;
+        REQ(pack_conv(h, w.rn[i].c1, *c1w, c1b, 1));
+        REQ(pack_conv(h, w.rn[i].c2, *c2w, c2b, 1));
+        REQ(pack_conv(h, w.rn[i].res, *rw, rb, 1));
+        REQ(upload_vec(h, m, p + ".block1.block.1.weight", &w.rn[i].g1));
+        REQ(upload_vec(h, m, p + ".block1.block.1.bias", &w.rn[i].b1));
+        REQ(upload_vec(h, m, p + ".block2.block.1.weight", &w.rn[i].g2));
+        REQ(upload_vec(h, m, p + ".block2.block.1.bias", &w.rn[i].b2));
+        mw.push_back(tw); mb.push_back(tb);
+    }
+    REQ(pack_linear_stack(h, w.tmlp, mw, mb));
+    for (int i = 0; i < 6; ++i) {
+        const std::string p = tr_names[i];
+        const HostTensor *q = T_(p + ".attn1.to_q.weight"), *k = T_(p + ".attn1.to_k.weight"), *v = T_(p + ".attn1.to_v.weight");
+        const HostTensor *ow = T_(p + ".attn1.to_out.0.weight"), *ob = T_(p + ".attn1.to_out.0.bias");
+        const HostTensor *f1w = T_(p + ".ff.net.0.proj.weight"), *f1b = T_(p + ".ff.net.0.proj.bias");
+        const HostTensor *f2w = T_(p + ".ff.net.2.weight"), *f2b = T_(p + ".ff.net.2.bias");
+        if (!q || !k || !v || !ow || !ob || !f1w || !f1b || !f2w || !f2b) return 1;
+        REQ(pack_linear_stack(h, w.tr[i].qkv, {q, k, v}, {}));
+        REQ(pack_linear_stack(h, w.tr[i].out, {ow}, {ob}));
+        REQ(pack_linear_stack(h, w.tr[i].ff1, {f1w}, {f1b}));
+        REQ(pack_linear_stack(h, w.tr[i].ff2, {f2w}, {f2b}));
+        REQ(upload_vec(h, m, p + ".norm1.weight", &w.tr[i].ln1g));
+        REQ(upload_vec(h, m, p + ".norm1.bias", &w.tr[i].ln1b));
+        REQ(upload_vec(h, m, p + ".norm3.weight", &w.tr[i].ln3g));
+        REQ(upload_vec(h, m, p + ".norm3.bias", &w.tr[i].ln3b));
+        // derived by the host loader with torch ops (transformer.py:71-78): exp(alpha), 1/(exp(beta)+1e-9)
+        REQ(upload_vec(h, m, p + ".ff.net.0.alpha_exp", &w.tr[i].alpha));
+        REQ(upload_vec(h, m, p + ".ff.net.0.beta_inv", &w.tr[i].binv));
+        if (w.tr[i].qkv.Cout != 3 * h->dims.heads * 64) return fail(h, "qkv width %d != 3*heads*64", w.tr[i].qkv.Cout);
+    }
+    {
+        const HostTensor *d0w = T_("down_blocks.0.2.conv.weight"), *d0b = T_("down_blocks.0.2.conv.bias");
+        const HostTensor *d1w = T_("down_blocks.1.2.weight"), *d1b = T_("down_blocks.1.2.bias");
+        const HostTensor *u0w = T_("up_blocks.0.2.conv.weight"), *u0b = T_("up_blocks.0.2.conv.bias");
+        const HostTensor *u1w = T_("up_blocks.1.2.weight"), *u1b = T_("up_blocks.1.2.bias");
+        const HostTensor *fw = T_("final_block.block.0.weight"), *fb = T_("final_block.block.0.bias");
+        const HostTensor *pw = T_("final_proj.weight"), *pb = T_("final_proj.bias");
+        if (!d0w || !d0b || !d1w || !d1b || !u0w || !u0b || !u1w || !u1b || !fw || !fb || !pw || !pb) return 1;
+        REQ(pack_conv_stride2(h, w.down0, *d0w, d0b));
+        REQ(pack_conv(h, w.down1, *d1w, d1b, 1));
+        REQ(pack_convT(h, w.up0, *u0w, u0b, 2, 1));
+        REQ(pack_conv(h, w.up1, *u1w, u1b, 1));
+        REQ(pack_conv(h, w.fin_conv, *fw, fb, 1));
+        REQ(pack_conv(h, w.fin_proj, *pw, pb, 1));
+        REQ(upload_vec(h, m, "final_block.block.1.weight", &w.fin_g));
+        REQ(upload_vec(h, m, "final_block.block.1.bias", &w.fin_b));
+    }
+    w.loaded = true;
+    return 0;
+}
+
+int ev_load_vocoder(ev_handle* h, const float* blob, const ev_tensor_index* index, size_t n) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    TensorMap m;
+    if (build_map(h, blob, index, n, m)) return 1;
+    VocoderW& v = h->voc;
+    v.loaded = false;
+    const int rates[4] = {8, 8, 2, 2}, ksz[4] = {16, 16, 4, 4}, rk[3] = {3, 7, 11}, rd[3] = {1, 3, 5};
+    const HostTensor *pw = T_("conv_pre.weight"), *pb = T_("conv_pre.bias"), *qw = T_("conv_post.weight"), *qb = T_("conv_post.bias");
+    if (!pw || !pb || !qw || !qb) return 1;
+    REQ(pack_conv(h, v.pre, *pw, pb, 1));
+    REQ(pack_conv(h, v.post, *qw, qb, 1));
+    v.ch[0] = (int)pw->shape[0];
+    for (int i = 0; i < 4; ++i) {
+        char nm[64];
+        snprintf(nm, sizeof nm, "ups.%d.weight", i); const HostTensor* uw = T_(nm);
+        snprintf(nm, sizeof nm, "ups.%d.bias", i); const HostTensor* ub = T_(nm);
+        if (!uw || !ub) return 1;
+        if ((int)uw->shape[2] != ksz[i]) return fail(h, "ups.%d kernel %d != %d", i, (int)uw->shape[2], ksz[i]);
+        REQ(pack_convT(h, v.ups[i], *uw, ub, rates[i], (ksz[i] - rates[i]) / 2));
+        v.ch[i + 1] = (int)uw->shape[1];
+        for (int j = 0; j < 3; ++j)
+            for (int mm = 0; mm < 3; ++mm) {
+                snprintf(nm, sizeof nm, "resblocks.%d.convs1.%d.weight", i * 3 + j, mm); const HostTensor* w1 = T_(nm);
+                snprintf(nm, sizeof nm, "resblocks.%d.convs1.%d.bias", i * 3 + j, mm); const HostTensor* b1 = T_(nm);
+                snprintf(nm, sizeof nm, "resblocks.%d.convs2.%d.weight", i * 3 + j, mm); const HostTensor* w2 = T_(nm);
+                snprintf(nm, sizeof nm, "resblocks.%d.convs2.%d.bias", i * 3 + j, mm); const HostTensor* b2 = T_(nm);
+                if (!w1 || !b1 || !w2 || !b2) return 1;
+                if ((int)w1->shape[2] != rk[j]) return fail(h, "resblock kernel mismatch");
+                REQ(pack_conv(h, v.c1[i * 3 + j][mm], *w1, b1, rd[mm]));
+                REQ(pack_conv(h, v.c2[i * 3 + j][mm], *w2, b2, 1));
+            }
+    }
+    v.loaded = true;
+    return 0;
+}
+#undef T_
+#undef REQ
+
+size_t ev_workspace_bytes(ev_handle* h, int B, int Tp_cfm, int T_voc) {
+    if (!h || B <= 0) return 0;
+    return plan_all(h, nullptr, B, Tp_cfm, T_voc, nullptr, nullptr);
+}
+
+static int check_cfm_args(ev_handle* h, int B, int Tp) {
+    if (!h->est.loaded) return fail(h, "estimator weights not loaded");
+    if (B <= 0 || Tp <= 0 || (Tp & 3)) return fail(h, "bad shape B=%d Tp=%d (Tp must be a positive multiple of 4)", B, Tp);
+    return 0;
+}
+
+int ev_cfm_decode(ev_handle* h, const float* d_mu, const int32_t* d_lengths, const float* d_spk, const float* d_z,
+                  int B, int Tp, int n_steps, float out_scale, float out_shift, float* d_out, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (check_cfm_args(h, B, Tp)) return 1;
+    if (n_steps <= 0 || n_steps > MAX_STEPS_PLAN) return fail(h, "n_steps %d out of range [1,%d]", n_steps, MAX_STEPS_PLAN);
+    if (!d_mu || !d_z || !d_out || (h->dims.spk_emb_dim > 0 && !d_spk)) return fail(h, "null tensor argument");
+    h->stream = (hipStream_t)stream;
+    EstBufs b;
+    if (ensure_ws(h, B, Tp, 0, &b, nullptr)) return 1;
+    // time grid exactly as torch.linspace(0, 1, n+1) + the running t / dt of solve_euler (flow_matching.py:52,70-83), in fp32
+    const int steps = n_steps + 1;
+    std::vector<float> span(steps);
+    {
+        const float stepf = (1.0f - 0.0f) / (float)(steps - 1);
+        const int halfway = steps / 2;
+        for (int i = 0; i < steps; ++i) span[i] = (i < halfway) ? (0.0f + stepf * (float)i) : (1.0f - stepf * (float)(steps - i - 1));
+    }
+    std::vector<float> ts(n_steps), dts(n_steps);
+    {
+        float t = span[0], dt = span[1] - span[0];
+        for (int s = 1; s <= n_steps; ++s) {
+            ts[s - 1] = t; dts[s - 1] = dt;
+            t = t + dt;
+            if (s < n_steps) dt = span[s + 1] - t;
+        }
+    }
+    if (prep_inputs(h, b, d_z, d_mu, d_lengths, d_spk, B, Tp)) return 1;
+    if (run_time_mlp(h, b, ts)) return 1;
+    for (int s = 0; s < n_steps; ++s)
+        if (run_estimator(h, b, s, dts[s], true)) return 1;
+    dim3 grid((Tp + 31) / 32, (80 + 31) / 32, B);
+    hipLaunchKernelGGL(fm_to_cm_kernel, grid, dim3(256), 0, h->stream, (const float*)b.state, 80, 0, d_out, 80, Tp, b.g0.S, b.g0.P, out_scale, out_shift);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int ev_estimator(ev_handle* h, const float* d_x, const float* d_mu, const int32_t* d_lengths, const float* d_spk, float t,
+                 int B, int Tp, float* d_v, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (check_cfm_args(h, B, Tp)) return 1;
+    h->stream = (hipStream_t)stream;
+    EstBufs b;
+    if (ensure_ws(h, B, Tp, 0, &b, nullptr)) return 1;
+    if (prep_inputs(h, b, d_x, d_mu, d_lengths, d_spk, B, Tp)) return 1;
+    if (run_time_mlp(h, b, std::vector<float>(1, t))) return 1;
+    if (run_estimator(h, b, 0, 0.f, false)) return 1;
+    dim3 grid((Tp + 31) / 32, (80 + 31) / 32, B);
+    hipLaunchKernelGGL(fm_to_cm_kernel, grid, dim3(256), 0, h->stream, (const float*)b.V0, 80, 0, d_v, 80, Tp, b.g0.S, b.g0.P, 1.0f, 0.0f);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->voc.loaded) return fail(h, "vocoder weights not loaded");
+    if (B <= 0 || T <= 0 || !d_mel || !d_wav) return fail(h, "bad arguments B=%d T=%d", B, T);
+    h->stream = (hipStream_t)stream;
+    VocBufs v;
+    if (ensure_ws(h, B, 0, T, nullptr, &v)) return 1;
+    const VocoderW& w = h->voc;
+    dim3 grid((T + 31) / 32, (80 + 31) / 32, B);
+    hipLaunchKernelGGL(cm_to_fm_kernel, grid, dim3(256), 0, h->stream, d_mel, v.M0, 80, 0, 80, T, v.g[0].S, v.g[0].P, (const float*)nullptr, 1.0f);
+    HIPCHK(h, hipGetLastError());
+    {   // conv_pre, with the first leaky_relu (models.py:184) fused as the epilogue: only ups[0] consumes it
+        Epi e; e.act = ACT_LRELU; e.act_slope = 0.1f;
+        if (launch_conv(h, w.pre, v.M0, 80, v.C0, w.ch[0], v.g[0], e)) return 1;
+    }
+    const float* xin = v.C0;
+    int cin = w.ch[0];
+    for (int i = 0; i < 4; ++i) {
+        const int l = i + 1, C = w.ch[l], s = w.ups[i].Cout / C;
+        {   // transposed conv: input frames of level l-1 -> view rows of s output frames each
+            Epi e;
+            if (launch_conv(h, w.ups[i], xin, cin, v.U[l], s * C, v.g[l - 1], e)) return 1;
+        }
+        for (int j = 0; j < 3; ++j) {
+            const float* x = v.U[l];
+            float* pp[2] = {v.Pa[l], v.Pb[l]};
+            for (int mm = 0; mm < 3; ++mm) {
+                Epi e1; e1.pro_slope = 0.1f; e1.act = ACT_LRELU; e1.act_slope = 0.1f;   // lrelu -> c1 -> lrelu
+                if (launch_conv(h, w.c1[i * 3 + j][mm], x, C, v.T1[l], C, v.g[l], e1)) return 1;
+                Epi e2; e2.R = x; e2.ldr = C;                                          // c2 + x
+                float* y = pp[mm & 1];
+                if (mm == 2) {   // resblock output joins the running mean over the 3 kernel sizes (models.py:186-192)
+                    y = v.XS[l];
+                    e2.accum = (j > 0);
+                    if (j == 2) { e2.div3 = 1; e2.act2_lrelu = 1; e2.act2_slope = (i == 3) ? 0.01f : 0.1f; }  // next consumer's leaky_relu
+                }
+                if (launch_conv(h, w.c2[i * 3 + j][mm], v.T1[l], C, y, C, v.g[l], e2)) return 1;
+                x = y;
+            }
+        }
+        xin = v.XS[l];
+        cin = C;
+    }
+    {   // conv_post + tanh, then strip the pads into (B, 256 T)
+        Epi e; e.act = ACT_TANH;
+        if (launch_conv(h, w.post, v.XS[4], w.ch[4], v.T1[4], 1, v.g[4], e)) return 1;
+        const size_t total = (size_t)B * v.g[4].T;
+        hipLaunchKernelGGL(strip_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, (const float*)v.T1[4], d_wav, v.g[4].T, v.g[4].S, v.g[4].P, total);
+        HIPCHK(h, hipGetLastError());
+    }
+    return 0;
+}
+
+int ev_profile_enable(ev_handle* h, int on) {
+    if (!h) return 1;
+    h->prof = on != 0;
+    h->ev_used = 0; h->prof_flops = 0; h->prof_launches = 0;
+    return 0;
+}
+
+int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* conv_launches, int reset) {
+    if (!h) return 1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double ms = 0;
+    for (size_t i = 0; i + 1 < h->ev_used; i += 2) {
+        float t = 0;
+        HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[i], h->ev_pool[i + 1]));
+        ms += t;
+    }
+    if (conv_ms) *conv_ms = ms;
+    if (conv_flops) *conv_flops = h->prof_flops;
+    if (conv_launches) *conv_launches = h->prof_launches;
+    if (reset) { h->ev_used = 0; h->prof_flops = 0; h->prof_launches = 0; }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// operator-level entry points for unit parity tests
+// ---------------------------------------------------------------------------
+int ev_op_conv1d(ev_handle* h, const float* d_x, const float* w, const float* bias, int B, int Cin, int T, int Cout, int K,
+                 int dilation, int transposed, int stride, int padding, float pre_lrelu_slope, float* d_y, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->stream = (hipStream_t)stream;
+    ConvLayer L;
+    HostTensor wt, bt;
+    wt.p = w; wt.ndim = 3;
+    bt.p = bias; bt.ndim = 1;
+    int Tout = T, P = 0;
+    size_t owned0 = h->owned.size();
+    if (!transposed && stride == 1) {
+        wt.shape[0] = Cout; wt.shape[1] = Cin; wt.shape[2] = K; bt.shape[0] = Cout;
+        if (padding != (K * dilation - dilation) / 2) return fail(h, "only 'same' padding is supported");
+        if (pack_conv(h, L, wt, bias ? &bt : nullptr, dilation)) return 1;
+    } else if (!transposed && stride == 2) {
+        wt.shape[0] = Cout; wt.shape[1] = Cin; wt.shape[2] = K; bt.shape[0] = Cout;
+        if (K != 3 || padding != 1 || (T & 1)) return fail(h, "stride-2 conv: k=3, p=1, even T");
+        if (pack_conv_stride2(h, L, wt, bias ? &bt : nullptr)) return 1;
+        Tout = T / 2;
+    } else {
+        wt.shape[0] = Cin; wt.shape[1] = Cout; wt.shape[2] = K; bt.shape[0] = Cout;
+        if (pack_convT(h, L, wt, bias ? &bt : nullptr, stride, padding)) return 1;
+        if ((K - 2 * padding) != stride) return fail(h, "transposed conv must satisfy K - 2p == stride");
+        Tout = T * stride;
+    }
+    // geometry: pads large enough for the halo, compatible with the view factor
+    const int vf = (!transposed && stride == 2) ? 2 : 1;
+    P = 32;
+    int rc = 0;
+    float *X = nullptr, *Y = nullptr;
+    do {
+        Geom gin{B * (T + 2 * P), T + 2 * P, P, T};
+        const int Pout = transposed ? P * stride : P / vf;
+        Geom gout{B * (Tout + 2 * Pout), Tout + 2 * Pout, Pout, Tout};
+        const size_t nx = (size_t)gin.nrows * Cin, ny = (size_t)gout.nrows * Cout;
+        if (hipMalloc((void**)&X, nx * 4) != hipSuccess || hipMalloc((void**)&Y, ny * 4) != hipSuccess) { rc = fail(h, "hipMalloc failed"); break; }
+        hipMemsetAsync(X, 0, nx * 4, h->stream);
+        hipMemsetAsync(Y, 0, ny * 4, h->stream);
+        dim3 g1((T + 31) / 32, (Cin + 31) / 32, B);
+        hipLaunchKernelGGL(cm_to_fm_kernel, g1, dim3(256), 0, h->stream, d_x, X, Cin, 0, Cin, T, gin.S, gin.P, (const float*)nullptr, 1.0f);
+        Epi e; e.pro_slope = pre_lrelu_slope;
+        if (transposed) {
+            rc = launch_conv(h, L, X, Cin, Y, stride * Cout, gin, e);   // view rows = input frames
+        } else if (stride == 2) {
+            Geom gv{gin.nrows / 2, gin.S / 2, gin.P / 2, T / 2};
+            rc = launch_conv(h, L, X, 2 * Cin, Y, Cout, gv, e);
+        } else {
+            rc = launch_conv(h, L, X, Cin, Y, Cout, gin, e);
+        }
+        if (rc) break;
+        dim3 g2((Tout + 31) / 32, (Cout + 31) / 32, B);
+        hipLaunchKernelGGL(fm_to_cm_kernel, g2, dim3(256), 0, h->stream, (const float*)Y, Cout, 0, d_y, Cout, Tout, gout.S, gout.P, 1.0f, 0.0f);
+        if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, "sync failed: %s", hipGetErrorString(hipGetLastError()));
+    } while (0);
+    if (X) hipFree(X);
+    if (Y) hipFree(Y);
+    while (h->owned.size() > owned0) { hipFree(h->owned.back()); h->owned.pop_back(); }
+    return rc;
+}
+
+int ev_op_groupnorm_mish(ev_handle* h, const float* d_x, const float* d_gamma, const float* d_beta, const int32_t* d_lengths,
+                         int B, int C, int T, int groups, float* d_y, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->stream = (hipStream_t)stream;
+    if (groups != 8 || C != 256) return fail(h, "groupnorm op: C=256, groups=8 only");
+    Geom g{B * (T + 4), T + 4, 2, T};
+    float *X = nullptr, *Y = nullptr, *rm = nullptr;
+    const size_t n = (size_t)g.nrows * C;
+    HIPCHK(h, hipMalloc((void**)&X, n * 4)); HIPCHK(h, hipMalloc((void**)&Y, n * 4)); HIPCHK(h, hipMalloc((void**)&rm, g.nrows * 4));
+    hipMemsetAsync(X, 0, n * 4, h->stream); hipMemsetAsync(Y, 0, n * 4, h->stream);
+    hipLaunchKernelGGL(rowmask_kernel, dim3((g.nrows + 255) / 256), dim3(256), 0, h->stream, rm, d_lengths, g.nrows, g.S, g.P, g.T, 1);
+    dim3 g1((T + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(cm_to_fm_kernel, g1, dim3(256), 0, h->stream, d_x, X, C, 0, C, T, g.S, g.P, (const float*)nullptr, 1.0f);
+    int rc = launch_gn(h, X, C, Y, C, d_gamma, d_beta, rm, nullptr, nullptr, 0, g, C, 0);
+    hipLaunchKernelGGL(fm_to_cm_kernel, g1, dim3(256), 0, h->stream, (const float*)Y, C, 0, d_y, C, T, g.S, g.P, 1.0f, 0.0f);
+    hipStreamSynchronize(h->stream);
+    hipFree(X); hipFree(Y); hipFree(rm);
+    return rc;
+}
+
+int ev_op_layernorm(ev_handle* h, const float* d_x, const float* d_gamma, const float* d_beta, int rows, int C, float* d_y, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->stream = (hipStream_t)stream;
+    if (C != 256) return fail(h, "layernorm op: C=256 only");
+    Geom g{rows, rows, 0, rows};
+    return launch_ln(h, d_x, C, d_y, C, d_gamma, d_beta, g);
+}
+
+int ev_op_attention(ev_handle* h, const float* d_qkv, const int32_t* d_lengths, int B, int T, int heads, float* d_out, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->stream = (hipStream_t)stream;
+    Geom g{B * T, T, 0, T};
+    float* rm = nullptr;
+    HIPCHK(h, hipMalloc((void**)&rm, (size_t)g.nrows * 4));
+    hipLaunchKernelGGL(rowmask_kernel, dim3((g.nrows + 255) / 256), dim3(256), 0, h->stream, rm, d_lengths, g.nrows, g.S, g.P, g.T, 1);
+    int rc = launch_attn(h, d_qkv, 3 * heads * 64, d_out, heads * 64, rm, g, heads);
+    hipStreamSynchronize(h->stream);
+    hipFree(rm);
+    return rc;
+}
+
+}  // extern "C"

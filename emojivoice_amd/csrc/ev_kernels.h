@@ -1,0 +1,612 @@
+// Device kernels of the EmojiVoice hot path for gfx950 (MI355X, CDNA4).
+//
+// Data layout in HBM ("frame-major, padded"): every activation is a row-major
+// (rows, C) fp32 matrix whose row index n runs over the flattened padded time
+// axis of the batch: utterance b, frame t lives at row  n = b*S + P + t,  S = T + 2P.
+// The P pad rows around each utterance are zero for the lifetime of the buffer
+// (the workspace is zeroed when its shape changes and kernels only ever store
+// rows with 0 <= t < T), so they ARE the conv zero padding: a K-tap dilated
+// window is just K row offsets and tiles may straddle utterances.
+//
+// conv_gemm_kernel: implicit GEMM  Y[n, co] = sum_{tap, ci} W[tap][co][ci] * X[n + off[tap], ci]
+// on the fp32-input matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 FMA chain,
+// 157 TFLOP/s peak = the fp32 vector peak but 1 LDS dword per operand per 64 FLOP-lanes).
+//   A operand = weights  (rows = output channels), B operand = activations (cols = frames).
+// Both are staged to LDS as [row][32 k + 4 pad] so that one ds_read_b128 per lane
+// feeds four consecutive MFMAs (k = kk + 4*half + s, s = 0..3) with no bank conflicts
+// (row stride 36 dwords: 16 consecutive rows hit 16 distinct 4-bank slots).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define EV_MAX_TAPS 16
+#define EV_BK 32          // k (input-channel) chunk per LDS stage
+#define EV_LDK 36         // LDS row stride in floats (32 + 4 pad)
+#define EV_WROWS 128      // weight rows per LDS stage (= taps_per_stage * BM)
+#define EV_HALO 64        // max halo rows (lo + hi) an X tile may carry
+
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SILU = 3, ACT_MISH = 4, ACT_SNAKE = 5 };
+
+struct ConvParams {
+    const float* X; int ldx; int Cin;
+    int isplit_log2, isstride;              // input column ci lives at (ci >> isplit_log2)*isstride + (ci & (2^isplit_log2 - 1))
+    const float* W; int Mpad; int Kpad;     // packed [ntaps][Mpad][Kpad]
+    const float* bias;                      // [Cout] or null
+    float* Y; int ldy; int Cout;
+    int osplit_log2, osstride;              // same column split for Y / R / Y2 (pair views of a strided slice)
+    int mmul;                               // rowmask index = n*mmul + (co >> osplit_log2)
+    int nrows;                              // rows of the flattened padded axis (B*S)
+    int S, P, T;                            // store predicate: 0 <= (n % S) - P < T
+    int ntaps; int off[EV_MAX_TAPS];
+    int halo_lo, halo_hi;
+    const uint32_t* tapmask;                // per BM-row tile bitmask of non-zero taps, or null
+    int mtiles, ntiles;
+    float pro_slope; int pro_lrelu;         // prologue leaky-relu on X
+    // epilogue (order: +bias, act, *mask1, *scale, +R, +Yold, /3, lrelu2, *mask2)
+    int act; float act_slope; const float* act_a; const float* act_b;
+    int mask1; float scale; const float* R; int ldr; int accum; int div3;
+    int act2_lrelu; float act2_slope; int mask2;
+    const float* rowmask;
+    float* Y2; int ldy2;                    // optional second output = v * rowmask
+};
+
+__device__ __forceinline__ float ev_lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float ev_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float ev_mish(float x) { return x * tanhf(ev_softplus(x)); }
+__device__ __forceinline__ float ev_silu(float x) { return x / (1.f + expf(-x)); }
+
+__device__ __forceinline__ float ev_act(float v, int act, float slope, const float* a, const float* b, int co) {
+    switch (act) {
+        case ACT_LRELU: return ev_lrelu(v, slope);
+        case ACT_TANH: return tanhf(v);
+        case ACT_SILU: return ev_silu(v);
+        case ACT_MISH: return ev_mish(v);
+        case ACT_SNAKE: { float s = sinf(v * a[co]); return v + b[co] * (s * s); }
+        default: return v;
+    }
+}
+
+// XCD-aware bijective remap of the linear block id: blocks that share an XCD
+// (id % 8 equal) get a contiguous range of work items, so neighbouring tiles
+// (same X rows, adjacent halos) hit the same per-XCD L2.
+__device__ __forceinline__ int ev_xcd_remap(int id, int nwg) {
+    int q = nwg >> 3, r = nwg & 7, xcd = id & 7, within = id >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + within;
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+    constexpr int TM = BM / WAVES_M / 32;
+    constexpr int TN = BN / WAVES_N / 32;
+    constexpr int TPS = EV_WROWS / BM;  // taps per weight stage
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    static_assert(TM >= 1 && TN >= 1, "tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                  // [(BN + EV_HALO)][EV_LDK]
+    float* Ws = smem + (BN + EV_HALO) * EV_LDK;        // [EV_WROWS][EV_LDK]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.mtiles * p.ntiles;
+    const int work = ev_xcd_remap(blockIdx.x, nwg);
+    const int mt = work % p.mtiles;
+    const int nt = work / p.mtiles;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+
+    // tiles that contain no storable row (pure padding) do nothing
+    {
+        int t_first = (n0 % p.S) - p.P;  // may be negative
+        // first valid row at or after n0: if t_first in [0,T) -> valid; else next utterance start
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - (n0 % p.S) + p.P;
+        if (dist >= BN || n0 + dist >= p.nrows) return;
+    }
+
+    // active taps for this M tile: the idx-th set bit of the (wave-uniform) mask
+    uint32_t tmask = p.tapmask ? p.tapmask[mt] : 0xffffffffu;
+    tmask &= (p.ntaps >= 32) ? 0xffffffffu : ((1u << p.ntaps) - 1u);
+    const int nact = __builtin_popcount(tmask);
+    auto tap_at = [&](int idx) -> int {
+        uint32_t m = tmask;
+        for (int i = 0; i < idx; ++i) m &= m - 1u;  // drop the idx lowest set bits
+        return __builtin_ctz(m);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int xrows = BN + p.halo_lo + p.halo_hi;
+    const int srow = tid >> 3;          // staging row within a 32-row pass
+    const int sc4 = (tid & 7) * 4;      // staging column (floats)
+    const int nchunks = p.Kpad / EV_BK;
+    const int nstages = (nact + TPS - 1) / TPS;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();  // everyone done with the previous chunk's X tile (and W stage)
+        // ---- stage the X tile of this k-chunk (with the optional prologue leaky-relu)
+        {
+            const int c = ch * EV_BK + sc4;
+            const bool cok = c < p.Cin;
+            for (int r = srow; r < xrows; r += 32) {
+                const int gr = n0 - p.halo_lo + r;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (cok && gr >= 0 && gr < p.nrows)
+                    v = *(const f32x4*)(p.X + (size_t)gr * p.ldx + (size_t)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1)));
+                if (p.pro_lrelu) {
+                    v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                    v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                }
+                *(f32x4*)(Xs + r * EV_LDK + sc4) = v;
+            }
+        }
+        for (int st = 0; st < nstages; ++st) {
+            if (st > 0) __syncthreads();  // previous stage's W no longer read
+            // ---- stage EV_WROWS weight rows: TPS taps x BM output channels x 32 k
+#pragma unroll
+            for (int pass = 0; pass < EV_WROWS / 32; ++pass) {
+                const int r = pass * 32 + srow;
+                const int tl = r / BM, m = r % BM;
+                const int ti = st * TPS + tl;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ti < nact) {
+                    const int tap = tap_at(ti);
+                    v = *(const f32x4*)(p.W + ((size_t)tap * p.Mpad + m0 + m) * p.Kpad + ch * EV_BK + sc4);
+                }
+                *(f32x4*)(Ws + r * EV_LDK + sc4) = v;
+            }
+            __syncthreads();
+            // ---- MFMA over this stage
+#pragma unroll
+            for (int tl = 0; tl < TPS; ++tl) {
+                const int ti = st * TPS + tl;
+                if (ti < nact) {
+                    const int tap = tap_at(ti);
+                    int toff = 0;
+#pragma unroll
+                    for (int q = 0; q < EV_MAX_TAPS; ++q) toff = (tap == q) ? p.off[q] : toff;   // static indexing keeps p in SGPRs
+                    const int off = toff + p.halo_lo;
+                    const float* arow = Ws + (tl * BM + wm * (TM * 32) + li) * EV_LDK + 4 * lh;
+                    const float* brow = Xs + (wn * (TN * 32) + li + off) * EV_LDK + 4 * lh;
+#pragma unroll
+                    for (int kk = 0; kk < EV_BK; kk += 8) {
+                        f32x4 a[TM], b[TN];
+#pragma unroll
+                        for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(arow + i * 32 * EV_LDK + kk);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(brow + j * 32 * EV_LDK + kk);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+#pragma unroll
+                            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                                for (int j = 0; j < TN; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 tile: col = lane&31 (frame), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Each wave transposes one 32-frame slab of its tile through LDS into [frame][channel] so that the
+    // fused epilogue runs on whole float4 channel groups and stores 16 lanes x 16 B contiguous per frame.
+    constexpr int EC = TM * 32;          // channels of the wave's sub-tile
+    constexpr int ELD = EC + 4;          // LDS row stride
+    constexpr int C4 = EC / 4;           // float4 groups per frame
+    constexpr int RPP = 64 / C4;         // frames per pass of the wave
+    float* Es = smem + wave * (32 * ELD);
+    const bool vec_ok = ((p.ldy & 3) == 0) && ((p.Cout & 3) == 0) && ((p.osstride & 3) == 0) && (!p.R || (p.ldr & 3) == 0) &&
+                        (!p.Y2 || (p.ldy2 & 3) == 0);
+    const int omask = (p.osplit_log2 >= 31) ? 0x7fffffff : ((1 << p.osplit_log2) - 1);
+    const int er = lane / C4;            // frame within a pass
+    const int ec = (lane % C4) * 4;      // channel offset inside the sub-tile
+    const int co = m0 + wm * EC + ec;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        __syncthreads();                 // LDS free (K loop done / previous slab consumed)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 q = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *(f32x4*)(Es + li * ELD + i * 32 + 8 * g + 4 * lh) = q;
+            }
+        __syncthreads();
+        if (co < p.Cout) {
+            const int sp = (p.osplit_log2 >= 31) ? 0 : (co >> p.osplit_log2);
+            const size_t col = (size_t)sp * p.osstride + (co & omask);   // column offset inside a row
+            const bool full = vec_ok && (co + 3 < p.Cout);
+            float bs[4] = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bs[e] = p.bias[(co + e < p.Cout) ? co + e : p.Cout - 1];
+            }
+            for (int rr0 = 0; rr0 < 32; rr0 += RPP) {
+                const int rl = rr0 + er;
+                const int n = n0 + wn * (TN * 32) + j * 32 + rl;
+                if (n >= p.nrows) continue;
+                const int t = (n % p.S) - p.P;
+                if (t < 0 || t >= p.T) continue;
+                const f32x4 a = *(const f32x4*)(Es + rl * ELD + ec);
+                float v[4] = {a[0], a[1], a[2], a[3]};
+                const float rm = p.rowmask ? p.rowmask[(size_t)n * p.mmul + sp] : 1.f;
+                float rr[4] = {0.f, 0.f, 0.f, 0.f}, yo[4] = {0.f, 0.f, 0.f, 0.f};
+                if (full) {
+                    if (p.R) { f32x4 q = *(const f32x4*)(p.R + (size_t)n * p.ldr + col); rr[0] = q[0]; rr[1] = q[1]; rr[2] = q[2]; rr[3] = q[3]; }
+                    if (p.accum) { f32x4 q = *(const f32x4*)(p.Y + (size_t)n * p.ldy + col); yo[0] = q[0]; yo[1] = q[1]; yo[2] = q[2]; yo[3] = q[3]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e < p.Cout) {
+                            if (p.R) rr[e] = p.R[(size_t)n * p.ldr + col + e];
+                            if (p.accum) yo[e] = p.Y[(size_t)n * p.ldy + col + e];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (co + e < p.Cout) ? co + e : p.Cout - 1;
+                    float x = v[e] + bs[e];
+                    if (p.act) x = ev_act(x, p.act, p.act_slope, p.act_a, p.act_b, c);
+                    if (p.mask1) x *= rm;
+                    x *= p.scale;
+                    if (p.R) x += rr[e];
+                    if (p.accum) x += yo[e];
+                    if (p.div3) x = x / 3.0f;
+                    if (p.act2_lrelu) x = ev_lrelu(x, p.act2_slope);
+                    if (p.mask2) x *= rm;
+                    v[e] = x;
+                }
+                if (full) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    *(f32x4*)(p.Y + (size_t)n * p.ldy + col) = o;
+                    if (p.Y2) { f32x4 o2 = {v[0] * rm, v[1] * rm, v[2] * rm, v[3] * rm}; *(f32x4*)(p.Y2 + (size_t)n * p.ldy2 + col) = o2; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e < p.Cout) {
+                            p.Y[(size_t)n * p.ldy + col + e] = v[e];
+                            if (p.Y2) p.Y2[(size_t)n * p.ldy2 + col + e] = v[e] * rm;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Wave / block reductions (64-wide wavefronts)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float* red /*[4]*/) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------
+// GroupNorm(groups of CG channels over all T frames of one utterance, padded
+// frames included — decoder.py:41-43) + Mish + mask, then one of
+//   mode 0:  y = mish(gn(x)) * m
+//   mode 1:  y = (mish(gn(x)) * m + temb[c]) * m        (ResnetBlock1D block1 + time MLP, decoder.py:56-57)
+//   mode 2:  y = mish(gn(x)) * m + R[n][c]              (block2 + res_conv, decoder.py:58-60)
+// One workgroup per (utterance, group); wavefront shuffles for the reductions.
+// ---------------------------------------------------------------------------
+struct GNParams {
+    const float* X; int ldx; float* Y; int ldy;
+    const float* gamma; const float* beta;
+    const float* rowmask; const float* temb; const float* R; int ldr;
+    int S, P, T, CG; int mode; float eps;
+};
+
+__global__ __launch_bounds__(256) void groupnorm_mish_kernel(const GNParams p) {
+    __shared__ float red[4];
+    const int b = blockIdx.x, g = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int c4n = p.CG / 4;            // float4 columns per row
+    const int rpp = 256 / c4n;           // rows per pass
+    const int r0 = tid / c4n, c4 = (tid % c4n) * 4;
+    const size_t rowbase = (size_t)b * p.S + p.P;
+    const int cbase = g * p.CG + c4;
+    const float cnt = (float)p.T * (float)p.CG;
+
+    float s = 0.f;
+    for (int t = r0; t < p.T; t += rpp) {
+        f32x4 v = *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = block_sum_256(s, red) / cnt;
+    float q = 0.f;
+    for (int t = r0; t < p.T; t += rpp) {
+        f32x4 v = *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase);
+        float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    const float var = block_sum_256(q, red) / cnt;
+    const float rstd = 1.0f / sqrtf(var + p.eps);
+    float ga[4], be[4], te[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        ga[e] = p.gamma[cbase + e]; be[e] = p.beta[cbase + e];
+        te[e] = (p.mode == 1) ? p.temb[cbase + e] : 0.f;
+    }
+    for (int t = r0; t < p.T; t += rpp) {
+        const size_t n = rowbase + t;
+        f32x4 v = *(const f32x4*)(p.X + n * p.ldx + cbase);
+        const float m = p.rowmask[n];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float y = (v[e] - mean) * rstd * ga[e] + be[e];
+            y = ev_mish(y) * m;
+            if (p.mode == 1) y = (y + te[e]) * m;
+            o[e] = y;
+        }
+        if (p.mode == 2) {
+            f32x4 r = *(const f32x4*)(p.R + n * p.ldr + cbase);
+            o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3];
+        }
+        *(f32x4*)(p.Y + n * p.ldy + cbase) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over C = 256 channels of each valid frame (transformer.py norm1/norm3,
+// eps 1e-5, affine).  One wavefront per frame: 4 channels per lane, shuffle reduce.
+// ---------------------------------------------------------------------------
+struct LNParams {
+    const float* X; int ldx; float* Y; int ldy; const float* gamma; const float* beta;
+    int nrows, S, P, T; float eps;
+};
+
+__global__ __launch_bounds__(256) void layernorm256_kernel(const LNParams p) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.nrows) return;
+    const int t = (n % p.S) - p.P;
+    if (t < 0 || t >= p.T) return;
+    f32x4 v = *(const f32x4*)(p.X + (size_t)n * p.ldx + lane * 4);
+    float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+    float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f);
+    float rstd = 1.0f / sqrtf(var + p.eps);
+    f32x4 g = *(const f32x4*)(p.gamma + lane * 4);
+    f32x4 be = *(const f32x4*)(p.beta + lane * 4);
+    f32x4 o = {d0 * rstd * g[0] + be[0], d1 * rstd * g[1] + be[1], d2 * rstd * g[2] + be[2], d3 * rstd * g[3] + be[3]};
+    *(f32x4*)(p.Y + (size_t)n * p.ldy + lane * 4) = o;
+}
+
+// ---------------------------------------------------------------------------
+// Self-attention over mel frames, 64-dim heads, fp32 matrix cores, flash-style
+// online softmax.  Semantics of diffusers 0.25 Attention + SDPA with a FLOAT mask
+// (transformer.py:266-271): scores = q.k/8 + m[key], m = 1.0 for frames inside the
+// utterance length, 0.0 for padded frames (< Tp) — padded frames stay live keys.
+//
+// Per wave: 32 queries.  S^T = K.Q^T is computed with keys on the MFMA rows so the
+// score tile lands with the query on the lane and the 32 keys in the 16 registers
+// (x2 lane halves); each register is then directly the B operand of the P.V product
+// (O^T += V^T.P^T), no LDS round trip for P.
+// ---------------------------------------------------------------------------
+struct AttnParams {
+    const float* QKV; int ld;   // rows: [q(H*64) | k(H*64) | v(H*64)]
+    float* O; int ldo;          // rows: H*64
+    const float* rowmask;
+    int S, P, T, H; float scale;
+};
+
+#define ATT_LDK 68
+__global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) float Ks[32 * ATT_LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * ATT_LDK];
+    __shared__ float Ms[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const size_t rowbase = (size_t)b * p.S + p.P;
+    const int HD = p.H * 64;
+    const float* Qp = p.QKV + hd * 64;
+    const float* Kp = p.QKV + HD + hd * 64;
+    const float* Vp = p.QKV + 2 * HD + hd * 64;
+
+    // Q fragments: lane (query li, half lh) holds Q[q][8g + 4lh + s], pre-scaled
+    f32x4 qf[8];
+    {
+        const int tq = q0 + li;
+        const bool ok = tq < p.T;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *(const f32x4*)(Qp + (rowbase + tq) * p.ld + 8 * g + 4 * lh);
+            qf[g] = v * p.scale;
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float mrun = -1e30f, lrun = 0.f;
+
+    const int nkt = (p.T + 31) / 32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        // stage 32 keys x 64 dims of K and V (rows past T read zero pad / neighbour rows: finite, masked below)
+        {
+            const int r = tid >> 3;          // 0..31
+            const int c = (tid & 7) * 8;     // 0..56
+            const int tk = kt * 32 + r;
+            f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+            if (tk < p.T) {
+                const float* kr = Kp + (rowbase + tk) * p.ld + c;
+                const float* vr = Vp + (rowbase + tk) * p.ld + c;
+                k0 = *(const f32x4*)kr; k1 = *(const f32x4*)(kr + 4);
+                v0 = *(const f32x4*)vr; v1 = *(const f32x4*)(vr + 4);
+            }
+            *(f32x4*)(Ks + r * ATT_LDK + c) = k0; *(f32x4*)(Ks + r * ATT_LDK + c + 4) = k1;
+            *(f32x4*)(Vs + r * ATT_LDK + c) = v0; *(f32x4*)(Vs + r * ATT_LDK + c + 4) = v1;
+            if (tid < 32) {
+                const int tm = kt * 32 + tid;
+                Ms[tid] = (tm < p.T) ? p.rowmask[rowbase + tm] : -1e30f;
+            }
+        }
+        __syncthreads();
+        // S^T[key][q] = sum_d K[key][d] * Q[q][d]
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 a = *(const f32x4*)(Ks + li * ATT_LDK + 8 * g + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qf[g][e], s, 0, 0, 0);
+        }
+        // + mask[key]; key of register r on this lane half: (r&3) + 8*(r>>2) + 4*lh
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] += Ms[(r & 3) + 8 * (r >> 2) + 4 * lh];
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = expf(mrun - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - mnew); ps += s[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        // O^T[d][q] += sum_key V[key][d] * P^T[key][q]; register r pairs keys (kr, kr+4) across the lane halves
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float a0 = Vs[key * ATT_LDK + li];
+            const float a1 = Vs[key * ATT_LDK + 32 + li];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], o1, 0, 0, 0);
+        }
+    }
+    const int tq = q0 + li;
+    if (tq < p.T) {
+        const float inv = 1.0f / lrun;
+        float* orow = p.O + (rowbase + tq) * p.ldo + hd * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+            f32x4 c = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+            *(f32x4*)(orow + 8 * g + 4 * lh) = a;
+            *(f32x4*)(orow + 32 + 8 * g + 4 * lh) = c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Layout / elementwise helpers
+// ---------------------------------------------------------------------------
+// rowmask[n] = 1 if 0 <= t < ceil(len[b] / sub) (sub = 1: level-0 mask; sub = 2: mask[:, :, ::2]), else 0
+__global__ void rowmask_kernel(float* m, const int32_t* lengths, int nrows, int S, int P, int T, int sub) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= nrows) return;
+    int b = n / S, t = n % S - P;
+    int len = lengths ? lengths[b] : (T * sub);
+    int lim = (len + sub - 1) / sub;
+    m[n] = (t >= 0 && t < T && t < lim) ? 1.f : 0.f;
+}
+
+// (B, C, T) channel-major -> frame-major rows (b*S + P + t), columns [c0, c0+C), optional row mask and scale
+__global__ void cm_to_fm_kernel(const float* __restrict__ src, float* dst, int ld, int c0, int C, int T, int S, int P,
+                                const float* rowmask, float scale) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, cb = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        int c = cb + i, t = t0 + tx;
+        tile[i][tx] = (c < C && t < T) ? src[((size_t)b * C + c) * T + t] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int t = t0 + i, c = cb + tx;
+        if (t < T && c < C) {
+            size_t n = (size_t)b * S + P + t;
+            float v = tile[tx][i] * scale;
+            if (rowmask) v *= rowmask[n];
+            dst[n * ld + c0 + c] = v;
+        }
+    }
+}
+
+// frame-major -> (B, C, T) channel-major with out = v*scale + shift
+__global__ void fm_to_cm_kernel(const float* src, int ld, int c0, float* __restrict__ dst, int C, int T, int S, int P,
+                                float scale, float shift) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, cb = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        int t = t0 + i, c = cb + tx;
+        tile[i][tx] = (t < T && c < C) ? src[((size_t)b * S + P + t) * ld + c0 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        int c = cb + i, t = t0 + tx;
+        if (c < C && t < T) dst[((size_t)b * C + c) * T + t] = tile[tx][i] * scale + shift;
+    }
+}
+
+// broadcast a per-utterance vector (B, C) over all valid frames: dst[n][c0 + c] = v[b][c] * rowmask[n]
+__global__ void bcast_rows_kernel(const float* v, float* dst, int ld, int c0, int C, int nrows, int S, int P, int T,
+                                  const float* rowmask) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int n = idx / C, c = idx % C;
+    if (n >= nrows) return;
+    int b = n / S, t = n % S - P;
+    if (t < 0 || t >= T) return;
+    dst[(size_t)n * ld + c0 + c] = v[b * C + c] * (rowmask ? rowmask[n] : 1.f);
+}
+
+// sinusoidal time embedding (decoder.py:14-29) for a list of times: emb[i][0:half] = sin, [half:] = cos
+__global__ void time_sinusoid_kernel(const float* tvals, float* emb, int nt, int dim, float scale) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    int half = dim / 2;
+    if (idx >= nt * half) return;
+    int i = idx / half, k = idx % half;
+    float e = logf(10000.0f) / (float)(half - 1);
+    float f = expf((float)k * -e);
+    float a = (scale * tvals[i]) * f;
+    emb[(size_t)i * dim + k] = sinf(a);
+    emb[(size_t)i * dim + half + k] = cosf(a);
+}
+
+// frame-major (rows, C) -> flat waveform (B, T): C == 1 with pads stripped
+__global__ void strip_pad_kernel(const float* src, float* dst, int T, int S, int P, size_t total) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    size_t b = idx / T, t = idx % T;
+    dst[idx] = src[b * S + P + t];
+}

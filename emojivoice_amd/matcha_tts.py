@@ -1,0 +1,197 @@
+"""Drop-in for ``matcha.models.matcha_tts.MatchaTTS`` on the inference path.
+
+Keeps the reference call surface (matcha_tts.py:78, return keys :145-152):
+
+    MatchaTTS.synthesise(x, x_lengths, n_timesteps, temperature=1.0, spks=None, length_scale=1.0) -> dict
+
+``.n_spks``, ``.eval()``, ``.to(device)`` and ``MatchaTTS.load_from_checkpoint(path,
+map_location=)`` behave as the callers in cli.py / feel_me.py expect.  The text
+encoder, duration maths and alignment run as plain torch ops (host stage); the CFM
+Euler loop over the U-Net estimator runs in the HIP library through the C ABI
+(``ev_cfm_decode``).  Training (``forward``) is out of scope and raises.
+"""
+from __future__ import annotations
+
+import datetime as dt
+import pickle
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import weights as W
+from ._lib import Engine, EvLibraryError
+from .text_encoder import TextEncoder, fix_len_compatibility, generate_path, sequence_mask
+
+EST_PREFIX = "decoder.estimator."
+
+
+def estimator_tensors(sd: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+    """Estimator entries of a Matcha state dict with the prefix stripped, plus the two
+    derived SnakeBeta vectors the kernels consume (transformer.py:71-78, evaluated with the
+    same torch ops as the reference): ``alpha_exp = exp(alpha)``, ``beta_inv = 1/(exp(beta)+1e-9)``."""
+    out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for k, v in sd.items():
+        if not k.startswith(EST_PREFIX):
+            continue
+        name = k[len(EST_PREFIX):]
+        v = v.detach().to("cpu", torch.float32)
+        out[name] = v
+        if name.endswith(".ff.net.0.alpha"):
+            out[name + "_exp"] = torch.exp(v)
+        elif name.endswith(".ff.net.0.beta"):
+            out[name + "_inv"] = 1.0 / (torch.exp(v) + 0.000000001)
+    return out
+
+
+class MatchaTTS:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", n_heads_encoder: int = 2, n_layers_encoder: int = 6):
+        sd = {k: v.detach().float() for k, v in state_dict.items()}
+        self.n_spks = int(sd["spk_emb.weight"].shape[0]) if "spk_emb.weight" in sd else 1
+        self.spk_emb_dim = int(sd["spk_emb.weight"].shape[1]) if self.n_spks > 1 else 0
+        self.n_vocab = int(sd["encoder.emb.weight"].shape[0])
+        self.n_feats = int(sd["encoder.proj_m.weight"].shape[0])
+        self.mel_mean = float(sd.get("mel_mean", torch.tensor(0.0)))
+        self.mel_std = float(sd.get("mel_std", torch.tensor(1.0)))
+        self._cpu_sd = sd
+        self._enc_cfg = (n_heads_encoder, n_layers_encoder)
+        self.rng = "cpu"   # "cpu": z drawn exactly as the reference CPU run draws it (seed parity); "device": torch.cuda RNG
+        self.engine: Optional[Engine] = None
+        self.device = torch.device("cpu")
+        self.to(device)
+
+    # ---- nn.Module-like surface ------------------------------------------------
+    def eval(self):
+        return self
+
+    def to(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise EvLibraryError("emojivoice_amd.MatchaTTS runs on a ROCm GPU only (no CPU fallback); got device " + str(device))
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self._sd = {k: v.to(self.device) for k, v in self._cpu_sd.items() if not k.startswith(EST_PREFIX)}
+        self.encoder = TextEncoder(self._sd, *self._enc_cfg)
+        if self.engine is not None:
+            self.engine.close()
+        self.engine = Engine(idx, spk_emb_dim=self.spk_emb_dim)
+        self.engine.load_estimator(estimator_tensors(self._cpu_sd))
+        return self
+
+    def state_dict(self):
+        return dict(self._cpu_sd)
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None):
+        """cli.py:110-118.  A Lightning ``.ckpt`` is a pickle with ``state_dict`` and ``hyper_parameters``;
+        only tensors are needed here, so unknown classes in ``hyper_parameters`` (omegaconf, functools.partial
+        of an optimizer) are stubbed by a restricted unpickler instead of being imported."""
+        ckpt = _load_ckpt(checkpoint_path)
+        sd = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        return cls(sd, device=map_location if map_location is not None else "cuda:0")
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward (matcha_tts.py:154-246) is out of scope of the inference hot path")
+
+    # ---- the hot call ------------------------------------------------------------
+    @torch.inference_mode()
+    def synthesise(self, x, x_lengths, n_timesteps, temperature=1.0, spks=None, length_scale=1.0, *, z=None):
+        """Reference matcha_tts.py:77-152.  Extension: keyword-only ``z`` (unit normal, (B, 80, Tp)) replaces the
+        internal draw for bit-reproducible parity runs."""
+        t0 = dt.datetime.now()
+        dev = self.device
+        x, x_lengths = x.to(dev), x_lengths.to(dev)
+        if self.n_spks > 1:
+            spk = F.embedding(spks.to(dev).long(), self._sd["spk_emb.weight"])   # AttributeError on None, like the reference
+        else:
+            spk = None
+        mu_x, logw, x_mask = self.encoder(x, x_lengths, spk)
+        w = torch.exp(logw) * x_mask
+        w_ceil = torch.ceil(w) * length_scale
+        y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+        y_max_length = int(y_lengths.max())
+        y_max_length_ = fix_len_compatibility(y_max_length)
+        y_mask = sequence_mask(y_lengths, y_max_length_).unsqueeze(1).to(x_mask.dtype)
+        attn_mask = x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)
+        attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
+        mu_y = torch.matmul(attn.squeeze(1).transpose(1, 2), mu_x.transpose(1, 2)).transpose(1, 2)
+        encoder_outputs = mu_y[:, :, :y_max_length]
+
+        dec, mel = self.decode(mu_y, y_lengths, n_timesteps, temperature, spk, z=z)
+        dec = dec[:, :, :y_max_length]
+        mel = mel[:, :, :y_max_length]
+        t = (dt.datetime.now() - t0).total_seconds()
+        rtf = t * 22050 / (dec.shape[-1] * 256)
+        return {
+            "encoder_outputs": encoder_outputs,
+            "decoder_outputs": dec,
+            "attn": attn[:, :, :y_max_length],
+            "mel": mel,
+            "mel_lengths": y_lengths,
+            "rtf": rtf,
+        }
+
+    def draw_noise(self, B: int, Tp: int) -> torch.Tensor:
+        """The reference draws ``randn_like(mu_y)`` (flow_matching.py:51) where ``mu_y`` is a transposed view
+        (matcha_tts.py:134-135): the draw keeps those strides and uses torch's strided ``normal_`` path.  Doing
+        exactly that on the CPU reproduces the reference's noise for a given ``torch.manual_seed``."""
+        if self.rng == "device":
+            return torch.randn(B, Tp, self.n_feats, device=self.device).transpose(1, 2)
+        return torch.randn_like(torch.empty(B, Tp, self.n_feats).transpose(1, 2)).to(self.device)
+
+    def decode(self, mu_y, y_lengths, n_timesteps, temperature=1.0, spk=None, z=None):
+        """CFM.forward (flow_matching.py:32-53) + denormalize (utils/model.py:71-90) through the C ABI.
+        Returns (decoder_outputs, mel), both (B, 80, Tp)."""
+        B, _, Tp = mu_y.shape
+        if z is None:
+            z = self.draw_noise(B, Tp)
+        x0 = (z.to(self.device) * temperature).contiguous()
+        mu_c = mu_y.contiguous()
+        dec = self.engine.cfm_decode(mu_c, y_lengths, spk, x0, n_timesteps)
+        mel = dec * self.mel_std + self.mel_mean
+        return dec, mel
+
+
+# ---------------------------------------------------------------------------
+# checkpoint reading without lightning / omegaconf
+# ---------------------------------------------------------------------------
+class _Stub:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, *a, **k):
+        return self
+
+    def __setstate__(self, s):
+        pass
+
+
+class _RestrictedUnpickler(pickle.Unpickler):
+    _ALLOWED_PREFIXES = ("torch", "collections", "numpy", "builtins", "_codecs")
+
+    def find_class(self, module, name):
+        if module.split(".")[0] in self._ALLOWED_PREFIXES:
+            return super().find_class(module, name)
+        return _Stub
+
+
+class _PickleShim:
+    Unpickler = _RestrictedUnpickler
+    __name__ = "pickle"
+
+    @staticmethod
+    def load(f, **kw):
+        return _RestrictedUnpickler(f, **kw).load()
+
+
+def _load_ckpt(path):
+    try:
+        return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:  # noqa: BLE001 - hyper_parameters hold non-tensor classes
+        return torch.load(path, map_location="cpu", weights_only=False, pickle_module=_PickleShim)
+
+
+def synthetic(n_vocab: int = W.N_VOCAB_DEFAULT, n_spks: int = W.N_SPKS_EMOJI, device="cuda:0") -> MatchaTTS:
+    """Random-init model of the emoji architecture (no checkpoint exists offline)."""
+    return MatchaTTS(W.synthetic_matcha_state(n_vocab, n_spks), device=device)

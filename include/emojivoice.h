@@ -1,0 +1,114 @@
+/*
+ * emojivoice.h — C ABI of the MI355X-native EmojiVoice TTS hot path.
+ *
+ * The reference (rosielab/emojivoice, vendored Matcha-TTS) is pure Python on
+ * stock torch ops; it has no FFI of its own.  The entry points below are what a
+ * binding for its hot path replaces (paths relative to Matcha-TTS/matcha/):
+ *
+ *   ev_cfm_decode   <-  BASECFM.forward / solve_euler      models/components/flow_matching.py:32-85
+ *                       driving Decoder.forward            models/components/decoder.py:363-443
+ *                       (BasicTransformerBlock             models/components/transformer.py:243-316,
+ *                        diffusers Attention, SnakeBeta    transformer.py:17-80)
+ *   ev_hifigan      <-  Generator.forward                  hifigan/models.py:181-197
+ *                       (ResBlock1.forward                 hifigan/models.py:90-97)
+ *   ev_load_estimator <- MatchaTTS.load_from_checkpoint -> state_dict["decoder.estimator.*"]   cli.py:110-118
+ *   ev_load_vocoder   <- Generator.load_state_dict(ckpt["generator"]) + remove_weight_norm()   cli.py:84-90
+ *
+ * Conventions
+ *   - All tensors are fp32.  Pointers named d_* are DEVICE pointers owned by the
+ *     caller (PyTorch-ROCm in the shipped host layer); they are borrowed for the
+ *     duration of the call and all work is enqueued asynchronously on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream).
+ *   - The handle owns the re-laid-out weights and a workspace that grows on demand
+ *     (growth = hipMalloc, so the first call at a new (B,T) is not graph-capturable).
+ *   - Layout at the boundary is the reference's: mel-like tensors are (B, 80, T)
+ *     channel-major contiguous; waveforms are (B, 256*T) contiguous.
+ *   - Every function returns 0 on success, non-zero on failure; the message is
+ *     available from ev_last_error().  Nothing throws across this boundary.
+ *   - One handle per (device, stream user); calls on one handle are not thread-safe.
+ */
+#ifndef EMOJIVOICE_H
+#define EMOJIVOICE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EV_ABI_VERSION 1
+
+typedef struct ev_handle ev_handle;
+
+/* One tensor of a weight blob: `name` is the reference state_dict key with the
+ * module prefix stripped ("down_blocks.0.0.block1.block.0.weight", "conv_pre.weight" ...),
+ * `offset` is in floats from the start of the HOST blob. */
+typedef struct ev_tensor_index {
+    const char *name;
+    uint64_t offset;
+    int32_t ndim;
+    int64_t shape[4];
+} ev_tensor_index;
+
+/* Static model dimensions (reference configs/model/decoder/default.yaml, hifigan/config.py:1-28). */
+typedef struct ev_model_dims {
+    int32_t n_feats;       /* 80 */
+    int32_t spk_emb_dim;   /* 64 (0 for a single-speaker checkpoint) */
+    int32_t channels;      /* 256 */
+    int32_t heads;         /* 2 */
+    int32_t head_dim;      /* 64 */
+} ev_model_dims;
+
+int ev_abi_version(void);
+int ev_create(ev_handle **out, int device, const ev_model_dims *dims);
+void ev_destroy(ev_handle *h);
+const char *ev_last_error(ev_handle *h);
+
+/* Weights: host blob + index; copied and re-laid-out into library-owned device memory. */
+int ev_load_estimator(ev_handle *h, const float *blob, const ev_tensor_index *index, size_t n);
+int ev_load_vocoder(ev_handle *h, const float *blob, const ev_tensor_index *index, size_t n);
+
+/* Bytes of device workspace the two hot calls need at a given shape (0 on bad args). */
+size_t ev_workspace_bytes(ev_handle *h, int B, int Tp_cfm, int T_voc);
+
+/* Conditional-flow-matching ODE decode: n_steps Euler steps of the U-Net estimator.
+ *   d_mu      (B, 80, Tp)  aligned encoder output mu_y          (matcha_tts.py:134-135)
+ *   d_lengths (B) int32    valid frames per utterance (y_lengths; mask = t < length)
+ *   d_spk     (B, 64)      speaker/emoji embedding rows (NULL iff spk_emb_dim == 0)
+ *   d_z       (B, 80, Tp)  initial state x0 = noise * temperature (flow_matching.py:51)
+ *   d_out     (B, 80, Tp)  decoder output; out_scale/out_shift fuse denormalize()
+ *                          (utils/model.py:71-90): out = dec*out_scale + out_shift
+ *   Tp must be a multiple of 4 (fix_len_compatibility, utils/model.py:14-20). */
+int ev_cfm_decode(ev_handle *h, const float *d_mu, const int32_t *d_lengths, const float *d_spk, const float *d_z,
+                  int B, int Tp, int n_steps, float out_scale, float out_shift, float *d_out, void *stream);
+
+/* One estimator evaluation v = Decoder(x, mask, mu, t, spk)  (decoder.py:363-443). */
+int ev_estimator(ev_handle *h, const float *d_x, const float *d_mu, const int32_t *d_lengths, const float *d_spk,
+                 float t, int B, int Tp, float *d_v, void *stream);
+
+/* HiFi-GAN V1 generator: d_mel (B, 80, T) -> d_wav (B, 256*T), tanh output, no clamp/denoiser. */
+int ev_hifigan(ev_handle *h, const float *d_mel, int B, int T, float *d_wav, void *stream);
+
+/* Timing hooks for bench.py: HIP-event time (ms) of the dominant kernel family
+ * (fp32-MFMA implicit-GEMM conv) accumulated over the calls since the last reset,
+ * measured on the stream the kernels run on. */
+int ev_profile_enable(ev_handle *h, int on);
+int ev_profile_read(ev_handle *h, double *conv_ms, double *conv_flops, int64_t *conv_launches, int reset);
+
+/* ---- operator-level entry points (unit parity tests call these) ------------------
+ * Activations here are frame-major (rows, C) fp32 with an explicit row stride. */
+int ev_op_conv1d(ev_handle *h, const float *d_x /*(B,Cin,T)*/, const float *w /*HOST (Cout,Cin,K)*/,
+                 const float *bias /*HOST (Cout) or NULL*/, int B, int Cin, int T, int Cout, int K, int dilation,
+                 int transposed, int stride, int padding, float pre_lrelu_slope /*<0: none*/, float *d_y, void *stream);
+int ev_op_groupnorm_mish(ev_handle *h, const float *d_x /*(B,C,T)*/, const float *d_gamma, const float *d_beta,
+                         const int32_t *d_lengths, int B, int C, int T, int groups, float *d_y, void *stream);
+int ev_op_layernorm(ev_handle *h, const float *d_x /*(rows,C)*/, const float *d_gamma, const float *d_beta, int rows,
+                    int C, float *d_y, void *stream);
+int ev_op_attention(ev_handle *h, const float *d_qkv /*(B,T,3*heads*64)*/, const int32_t *d_lengths, int B, int T,
+                    int heads, float *d_out /*(B,T,heads*64)*/, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMOJIVOICE_H */
