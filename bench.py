@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""EmojiVoice hot-path benchmark (BASELINE.json: audio-seconds per second per GPU and real-time
+factor, 10 Euler steps, 22.05 kHz, batch 64 synthetic 6-s utterances).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = CFM decode (n Euler steps of the U-Net estimator) + HiFi-GAN on one batch of B utterances per
+GPU (inputs resident in HBM, z given, weights resident), plus — for N > 1 — the single RCCL all-gather that
+collates the waveforms.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+SR, HOP = 22050, 256
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+# SURVEY.md §8(d), measured on the reference modules: FLOPs and layer-granular activation bytes per 6-s utterance
+ALG_FLOP_PER_AUDIO_S = 62.5e9
+ALG_BYTES_PER_AUDIO_S = 520e6
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, min(n, int(os.environ.get("EV_CPU_THREADS", "32"))))
+
+
+def make_inputs(B_global, T, lo, hi, device):
+    """Config 2/3 inputs: global tensors from fixed seeds; this rank keeps rows [lo, hi)."""
+    from emojivoice_amd.emoji import EMOJI_MAPPING
+
+    mu = torch.randn(B_global, 80, T, generator=torch.Generator().manual_seed(1234))[lo:hi]
+    z = torch.randn(B_global, 80, T, generator=torch.Generator().manual_seed(1235))[lo:hi]
+    ids = torch.tensor(sorted(EMOJI_MAPPING.values()))
+    pick = torch.randint(0, len(ids), (B_global,), generator=torch.Generator().manual_seed(1236))[lo:hi]
+    spk_ids = ids[pick]
+    lengths = torch.full((hi - lo,), T, dtype=torch.int64)
+    return mu.to(device), z.to(device), spk_ids.to(device), lengths.to(device)
+
+
+def cpu_baseline(sd, voc_sd, mu, z0, spk, n_ode):
+    """The CPU oracle (restatement of the reference, pinned by reference-generated goldens) timed on this
+    box's host cores on a bounded sample (the first rows) of the same workload.  ``z0`` is already scaled
+    by the temperature."""
+    from emojivoice_amd import weights as W
+    from oracle import matcha_oracle as O
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    sample_b, _, T = mu.shape
+    log(f"[bench] cpu baseline: oracle on {cores} host threads, B={sample_b} ...")
+    mask = torch.ones(sample_b, 1, T)
+    t0 = time.perf_counter()
+    with torch.inference_mode():
+        dec = O.solve_euler(sd, z0, mu, mask, n_ode, spk)
+        mel = O.denormalize(dec, sd["mel_mean"], sd["mel_std"])
+        wav = O.hifigan_forward(voc_sd, mel, W.HIFIGAN_V1)
+    dt = time.perf_counter() - t0
+    audio_s = sample_b * T * HOP / SR
+    return {"value": round(audio_s / dt, 3), "unit": "audio_s/s", "cores": cores, "kind": "port",
+            "sample": f"first {sample_b} utterances of the batch (T={T} frames), {n_ode} Euler steps + HiFi-GAN, 1 call, {dt:.1f} s wall"}, mel, wav
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--frames", type=int, default=516, help="mel frames per utterance (516 = 5.99 s)")
+    ap.add_argument("--ode-steps", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=8)
+    args = ap.parse_args()
+
+    from emojivoice_amd import dist as D
+    from emojivoice_amd import weights as W
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+    from emojivoice_amd.matcha_tts import MatchaTTS
+
+    rank, world, local = D.init_from_env()
+    if world != args.gpus:
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    B, T, n_ode = args.batch, args.frames, args.ode_steps
+    assert T % 4 == 0
+    sd = W.synthetic_matcha_state()
+    voc_sd = W.synthetic_hifigan_state()
+    model = MatchaTTS(sd, device=device)
+    voc = Generator(AttrDict(v1)).to(device)
+    voc.load_state_dict(voc_sd)
+    lo, hi = D.shard_bounds(B * world, rank, world)
+    mu, z, spk_ids, lengths = make_inputs(B * world, T, lo, hi, device)
+    spk = model._sd["spk_emb.weight"][spk_ids]
+    z = z * 0.667
+
+    def step():
+        dec = model.engine.cfm_decode(mu, lengths, spk, z, n_ode, model.mel_std, model.mel_mean)   # denormalised mel
+        wav = voc(dec)
+        return D.all_gather_waveforms(wav) if world > 1 else wav
+
+    log(f"[bench] rank {rank}/{world}: weights loaded, B={B} T={T}; warmup {args.warmup} ...")
+    for _ in range(args.warmup):
+        tw = time.perf_counter()
+        step()
+        torch.cuda.synchronize()
+        log(f"[bench] warmup step {time.perf_counter() - tw:.3f} s")
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wav = step()
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    log(f"[bench] timed {args.steps} steps in {dt:.3f} s")
+    audio_s_total = args.steps * B * world * T * HOP / SR
+    value = audio_s_total / dt
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel family (fp32-MFMA implicit-GEMM conv), measured live with HIP events
+        # recorded on the launch stream around every conv launch of one extra, untimed-for-`value` step
+        for e in (model.engine, voc.engine):
+            e.profile_enable(True)
+        step()
+        torch.cuda.synchronize()
+        ms_c, fl_c, n_c = model.engine.profile_read()
+        ms_v, fl_v, n_v = voc.engine.profile_read()
+        for e in (model.engine, voc.engine):
+            e.profile_enable(False)
+        conv_ms, conv_fl, conv_n = ms_c + ms_v, fl_c + fl_v, n_c + n_v
+        achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        per_gpu = value / world
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "conv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                    "launches_per_step": int(conv_n), "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
+                    "alg_gflop_per_launch": round(conv_fl / max(conv_n, 1) / 1e9, 3),
+                    "conv_ms_per_step": round(conv_ms, 2), "conv_ms_cfm": round(ms_c, 2), "conv_ms_hifigan": round(ms_v, 2),
+                    "tflops_cfm_convs": round(fl_c / (ms_c * 1e-3) / 1e12, 2), "tflops_hifigan_convs": round(fl_v / (ms_v * 1e-3) / 1e12, 2)}
+        path_roof = {"fp32_frac": round(per_gpu * ALG_FLOP_PER_AUDIO_S / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
+                     "hbm_frac": round(per_gpu * ALG_BYTES_PER_AUDIO_S / (PEAK_HBM_GBS * 1e9), 4),
+                     "note": "whole-path fractions from SURVEY §8(d) per-audio-second work; the fp32 MFMA roof binds"}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            s = min(args.cpu_sample, B)
+            cpu, ref_mel, ref_wav = cpu_baseline(sd, voc_sd, mu[:s].cpu(), z[:s].cpu(), spk[:s].cpu(), n_ode)
+            # parity of the benchmarked configuration itself: the same rows decoded as their own batch on the GPU
+            dec_s = model.engine.cfm_decode(mu[:s], lengths[:s], spk[:s], z[:s], n_ode, model.mel_std, model.mel_mean)
+            wav_s = voc(dec_s)
+            cpu["parity_mel_linf"] = float((dec_s.cpu() - ref_mel).abs().max())
+            cpu["parity_wav_rms"] = float((wav_s.cpu() - ref_wav).pow(2).mean().sqrt())
+        out = {
+            "metric": "audio_seconds_per_second", "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config2: batch {B} x {T}-frame (5.99 s) utterances per GPU, {n_ode} Euler steps + HiFi-GAN V1, 22.05 kHz",
+                       "global_batch": B * world, "frames": T, "ode_steps": n_ode, "parallelism": f"dp{world}",
+                       "collective": "all_gather(waveforms)" if world > 1 else "none"},
+            "per_gpu_audio_s_per_s": round(per_gpu, 2), "rtf": round(1.0 / per_gpu, 6), "x_realtime_per_gpu": round(per_gpu, 1),
+            "roofline": roofline, "path_roofline": path_roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        D.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

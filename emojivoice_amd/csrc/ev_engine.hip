@@ -115,7 +115,19 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
     for (int i = 0; i < L.ntaps; ++i) { if (-L.off[i] > lo) lo = -L.off[i]; if (L.off[i] > hi) hi = L.off[i]; }
     L.halo_lo = lo; L.halo_hi = hi;
     if (lo + hi > EV_HALO) return fail(h, "conv halo %d exceeds EV_HALO", lo + hi);
-    if (dev_upload(h, Wh, &L.W)) return 1;
+    {   // re-order [tap][Mpad][Kpad] into MFMA-fragment order [tap][Mpad/32][Kpad/8][lane][4] (see conv_gemm_kernel)
+        std::vector<float> Wf(Wh.size());
+        const int MT32 = L.Mpad / 32, KG8 = L.Kpad / 8;
+        for (int tap = 0; tap < L.ntaps; ++tap)
+            for (int mt = 0; mt < MT32; ++mt)
+                for (int kg = 0; kg < KG8; ++kg)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = mt * 32 + (lane & 31), k = kg * 8 + 4 * (lane >> 5) + e;
+                            Wf[((((size_t)tap * MT32 + mt) * KG8 + kg) * 64 + lane) * 4 + e] = Wh[((size_t)tap * L.Mpad + row) * L.Kpad + k];
+                        }
+        if (dev_upload(h, Wf, &L.W)) return 1;
+    }
     if (bias) { if (dev_upload(h, *bias, &L.bias)) return 1; }
     // per-tile non-zero tap masks
     const int bms[3] = {128, 64, 32};
@@ -247,7 +259,7 @@ int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** o
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
 void launch_cfg(const ConvParams& p, hipStream_t st) {
-    const size_t smem = (size_t)((BN + EV_HALO) * EV_LDK + EV_WROWS * EV_LDK) * sizeof(float);
+    const size_t smem = (size_t)((BN + EV_HALO) * EV_LDK) * sizeof(float);
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 

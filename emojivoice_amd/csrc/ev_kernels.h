@@ -33,7 +33,7 @@ enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SILU = 3, ACT_MISH = 4, AC
 struct ConvParams {
     const float* X; int ldx; int Cin;
     int isplit_log2, isstride;              // input column ci lives at (ci >> isplit_log2)*isstride + (ci & (2^isplit_log2 - 1))
-    const float* W; int Mpad; int Kpad;     // packed [ntaps][Mpad][Kpad]
+    const float* W; int Mpad; int Kpad;     // fragment order [ntaps][Mpad/32][Kpad/8][64 lanes][4]
     const float* bias;                      // [Cout] or null
     float* Y; int ldy; int Cout;
     int osplit_log2, osstride;              // same column split for Y / R / Y2 (pair views of a strided slice)
@@ -82,12 +82,10 @@ template <int BM, int BN, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
-    constexpr int TPS = EV_WROWS / BM;  // taps per weight stage
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(TM >= 1 && TN >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                                  // [(BN + EV_HALO)][EV_LDK]
-    float* Ws = smem + (BN + EV_HALO) * EV_LDK;        // [EV_WROWS][EV_LDK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -135,70 +133,88 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const int srow = tid >> 3;          // staging row within a 32-row pass
     const int sc4 = (tid & 7) * 4;      // staging column (floats)
     const int nchunks = p.Kpad / EV_BK;
-    const int nstages = (nact + TPS - 1) / TPS;
 
+    // A operand (weights) never touches LDS: the host packs them in MFMA-fragment order
+    //   Wf[tap][row-tile of 32][k-group of 8][lane 64][4]   with lane = (row & 31) + 32*half, element s <-> k = 8*kg + 4*half + s,
+    // so one global_load_dwordx4 per wave reads a contiguous 1 KiB (L2-resident) fragment feeding four MFMAs per
+    // 32-row tile.  Fragments are prefetched one k-group ahead, across taps and k-chunks, so the waves of a
+    // workgroup only meet at the two barriers around each X-tile (activation) stage.
+    constexpr int XPASS = (BN + EV_HALO) / 32;
+    const int mt32 = (m0 + wm * (TM * 32)) >> 5;          // first 32-row tile of this wave
+    const int MT32 = p.Mpad >> 5, KG8 = p.Kpad >> 3;
+    const float* wlane = p.W + (size_t)lane * 4;
+    auto a_ptr = [&](int tap, int kg8) -> const float* {   // fragment of row-tile mt32 (+i) at absolute k-group kg8
+        return wlane + (((size_t)tap * MT32 + mt32) * KG8 + kg8) * 256;
+    };
+    f32x4 acur[TM], anext[TM];
+    if (nact > 0) {
+        const float* ap = a_ptr(tap_at(0), 0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acur[i] = *(const f32x4*)(ap + (size_t)i * KG8 * 256);
+    }
     for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();  // everyone done with the previous chunk's X tile (and W stage)
-        // ---- stage the X tile of this k-chunk (with the optional prologue leaky-relu)
+        __syncthreads();  // previous chunk's MFMAs are done with Xs
         {
+            // ---- stage the X tile of this k-chunk (with the optional prologue leaky-relu): all loads first
             const int c = ch * EV_BK + sc4;
             const bool cok = c < p.Cin;
-            for (int r = srow; r < xrows; r += 32) {
+            const float* xb = p.X + (size_t)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1));
+            f32x4 xv[XPASS];
+#pragma unroll
+            for (int q = 0; q < XPASS; ++q) {
+                const int r = q * 32 + srow;
                 const int gr = n0 - p.halo_lo + r;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cok && gr >= 0 && gr < p.nrows)
-                    v = *(const f32x4*)(p.X + (size_t)gr * p.ldx + (size_t)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1)));
+                if (cok && r < xrows && gr >= 0 && gr < p.nrows) v = *(const f32x4*)(xb + (size_t)gr * p.ldx);
+                xv[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < XPASS; ++q) {
+                const int r = q * 32 + srow;
+                f32x4 v = xv[q];
                 if (p.pro_lrelu) {
                     v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
                     v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
                 }
-                *(f32x4*)(Xs + r * EV_LDK + sc4) = v;
+                if (r < xrows) *(f32x4*)(Xs + r * EV_LDK + sc4) = v;
             }
         }
-        for (int st = 0; st < nstages; ++st) {
-            if (st > 0) __syncthreads();  // previous stage's W no longer read
-            // ---- stage EV_WROWS weight rows: TPS taps x BM output channels x 32 k
+        __syncthreads();
+        for (int ti = 0; ti < nact; ++ti) {
+            const int tap = tap_at(ti);
+            int toff = 0;
 #pragma unroll
-            for (int pass = 0; pass < EV_WROWS / 32; ++pass) {
-                const int r = pass * 32 + srow;
-                const int tl = r / BM, m = r % BM;
-                const int ti = st * TPS + tl;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ti < nact) {
-                    const int tap = tap_at(ti);
-                    v = *(const f32x4*)(p.W + ((size_t)tap * p.Mpad + m0 + m) * p.Kpad + ch * EV_BK + sc4);
+            for (int q = 0; q < EV_MAX_TAPS; ++q) toff = (tap == q) ? p.off[q] : toff;   // static indexing keeps p in SGPRs
+            const float* brow = Xs + (wn * (TN * 32) + li + toff + p.halo_lo) * EV_LDK + 4 * lh;
+            // where the fragment after this tap's last k-group lives (next tap, or first tap of the next chunk)
+            const bool last_tap = (ti + 1 == nact);
+            const int ntap = last_tap ? tap_at(0) : tap_at(ti + 1);
+            const int nkg8 = (last_tap ? ch + 1 : ch) * 4;
+            const bool have_next = !(last_tap && ch + 1 == nchunks);
+#pragma unroll
+            for (int kg = 0; kg < 4; ++kg) {
+                // prefetch the next k-group's A fragments
+                if (kg < 3) {
+                    const float* ap = a_ptr(tap, ch * 4 + kg + 1);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) anext[i] = *(const f32x4*)(ap + (size_t)i * KG8 * 256);
+                } else if (have_next) {
+                    const float* ap = a_ptr(ntap, nkg8);
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) anext[i] = *(const f32x4*)(ap + (size_t)i * KG8 * 256);
                 }
-                *(f32x4*)(Ws + r * EV_LDK + sc4) = v;
-            }
-            __syncthreads();
-            // ---- MFMA over this stage
+                f32x4 b[TN];
 #pragma unroll
-            for (int tl = 0; tl < TPS; ++tl) {
-                const int ti = st * TPS + tl;
-                if (ti < nact) {
-                    const int tap = tap_at(ti);
-                    int toff = 0;
+                for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(brow + j * 32 * EV_LDK + kg * 8);
 #pragma unroll
-                    for (int q = 0; q < EV_MAX_TAPS; ++q) toff = (tap == q) ? p.off[q] : toff;   // static indexing keeps p in SGPRs
-                    const int off = toff + p.halo_lo;
-                    const float* arow = Ws + (tl * BM + wm * (TM * 32) + li) * EV_LDK + 4 * lh;
-                    const float* brow = Xs + (wn * (TN * 32) + li + off) * EV_LDK + 4 * lh;
+                for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                    for (int kk = 0; kk < EV_BK; kk += 8) {
-                        f32x4 a[TM], b[TN];
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int i = 0; i < TM; ++i) a[i] = *(const f32x4*)(arow + i * 32 * EV_LDK + kk);
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[i][s4], b[j][s4], acc[i][j], 0, 0, 0);
 #pragma unroll
-                        for (int j = 0; j < TN; ++j) b[j] = *(const f32x4*)(brow + j * 32 * EV_LDK + kk);
-#pragma unroll
-                        for (int s = 0; s < 4; ++s)
-#pragma unroll
-                            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                                for (int j = 0; j < TN; ++j)
-                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-                    }
-                }
+                for (int i = 0; i < TM; ++i) acur[i] = anext[i];
             }
         }
     }
