@@ -10,6 +10,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -44,6 +45,7 @@ struct Epi {
     int act2_lrelu = 0; float act2_slope = 0.f; int mask2 = 0; const float* rowmask = nullptr; int mmul = 1;
     float* Y2 = nullptr; int ldy2 = 0;
     float pro_slope = -1.f;                 // >= 0: prologue leaky-relu on the input
+    int dbg = 0; int force_cfg = -1;
     int isplit_log2 = 31, isstride = 0;     // input column split (pair view of a strided slice)
     int osplit_log2 = 31, osstride = 0;     // output column split
 };
@@ -259,7 +261,9 @@ int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** o
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN>
 void launch_cfg(const ConvParams& p, hipStream_t st) {
-    const size_t smem = (size_t)((BN + EV_HALO) * EV_LDK) * sizeof(float);
+    // LDS holds the X tile during the K loop and, afterwards, one transposed 32-frame slab per wave for the epilogue
+    constexpr size_t xs = (size_t)(BN + EV_HALO) * EV_LDK, es = (size_t)4 * 32 * (BM / WM + 4);
+    const size_t smem = (xs > es ? xs : es) * sizeof(float);
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
@@ -276,7 +280,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     p.act = e.act; p.act_slope = e.act_slope; p.act_a = e.act_a; p.act_b = e.act_b;
     p.mask1 = e.mask1; p.scale = e.scale; p.R = e.R; p.ldr = e.ldr; p.accum = e.accum; p.div3 = e.div3;
     p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope; p.mask2 = e.mask2; p.rowmask = e.rowmask;
-    p.Y2 = e.Y2; p.ldy2 = e.ldy2;
+    p.Y2 = e.Y2; p.ldy2 = e.ldy2; p.dbg = e.dbg;
     if ((ldx & 3) || (L.Cin & 3)) return fail(h, "conv input must be float4-aligned (ldx %d Cin %d)", ldx, L.Cin);
 
     // tile choice: BM by output width; fall back to smaller tiles when the grid would not fill 256 CUs twice
@@ -287,6 +291,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         const long wgs128 = (long)(L.Mpad / 128) * ((g.nrows + 127) / 128);
         cfg = (wgs128 >= 512 || L.Cout % 128 != 0) ? 0 : 1;
     }
+    if (e.force_cfg >= 0) cfg = e.force_cfg;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         if (h->ev_used + 2 > h->ev_pool.size()) {
@@ -868,6 +873,49 @@ int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* 
     if (conv_launches) *conv_launches = h->prof_launches;
     if (reset) { h->ev_used = 0; h->prof_flops = 0; h->prof_launches = 0; }
     return 0;
+}
+
+// Kernel microbenchmark hook (tools/conv_bench.py): times `iters` launches of one resblock-style conv
+// (prologue lrelu, bias, residual) at a given geometry with HIP events; dbg = ablation bits, cfg = forced tile config.
+int ev_dbg_conv_bench(ev_handle* h, int Cin, int Cout, int K, int dil, int B, int T, int P, int iters, int dbg, int cfg, float* ms_out) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->stream = nullptr;
+    std::vector<float> w((size_t)Cout * Cin * K), b(Cout);
+    unsigned s = 12345u;
+    for (auto& v : w) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.0f / 16777216.0f) - 0.5f) * 0.1f; }
+    for (auto& v : b) { s = s * 1664525u + 1013904223u; v = ((s >> 8) * (1.0f / 16777216.0f) - 0.5f); }
+    HostTensor wt, bt;
+    wt.p = w.data(); wt.ndim = 3; wt.shape[0] = Cout; wt.shape[1] = Cin; wt.shape[2] = K;
+    bt.p = b.data(); bt.ndim = 1; bt.shape[0] = Cout;
+    ConvLayer L;
+    size_t owned0 = h->owned.size();
+    if (pack_conv(h, L, wt, &bt, dil)) return 1;
+    Geom g{B * (T + 2 * P), T + 2 * P, P, T};
+    float *X = nullptr, *Y = nullptr;
+    const size_t nx = (size_t)g.nrows * Cin, ny = (size_t)g.nrows * Cout;
+    HIPCHK(h, hipMalloc((void**)&X, nx * 4));
+    HIPCHK(h, hipMalloc((void**)&Y, ny * 4));
+    std::vector<float> xh(std::min(nx, (size_t)1 << 22));
+    for (auto& v : xh) { s = s * 1664525u + 1013904223u; v = (s >> 8) * (1.0f / 16777216.0f) - 0.5f; }
+    for (size_t o = 0; o < nx; o += xh.size()) HIPCHK(h, hipMemcpy(X + o, xh.data(), std::min(xh.size(), nx - o) * 4, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemset(Y, 0, ny * 4));
+    Epi e; e.pro_slope = 0.1f; e.dbg = dbg; e.force_cfg = cfg;
+    if (Cin == Cout) { e.R = X; e.ldr = Cin; }
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    int rc = launch_conv(h, L, X, Cin, Y, Cout, g, e);   // warm-up
+    HIPCHK(h, hipEventRecord(e0, nullptr));
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(h, L, X, Cin, Y, Cout, g, e);
+    HIPCHK(h, hipEventRecord(e1, nullptr));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    if (ms_out) *ms_out = ms / (float)iters;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    hipFree(X); hipFree(Y);
+    while (h->owned.size() > owned0) { hipFree(h->owned.back()); h->owned.pop_back(); }
+    return rc;
 }
 
 // ---------------------------------------------------------------------------
