@@ -1,0 +1,98 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/emojivoice.h declares (no compute
+calls without a GPU), host logic (emoji rule, sharding, weight tables, text-encoder host stage vs the oracle)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from emojivoice_amd import _lib, emoji
+from emojivoice_amd import weights as W
+from oracle import matcha_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(REPO, "include", "emojivoice.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ev_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build_library()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/emojivoice.h but not exported"
+    assert set(names) == set(_lib.EXPORTS)
+    lib.ev_abi_version.restype = ctypes.c_int
+    assert lib.ev_abi_version() == 1
+
+
+def test_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.EvLibraryError):
+        _lib.Engine(0)
+    from emojivoice_amd.matcha_tts import MatchaTTS
+
+    with pytest.raises(_lib.EvLibraryError):
+        MatchaTTS(W.synthetic_matcha_state(), device="cpu")
+
+
+def test_product_never_imports_oracle():
+    import glob
+
+    for f in glob.glob(os.path.join(REPO, "emojivoice_amd", "**", "*.py"), recursive=True):
+        txt = open(f).read()
+        assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_emoji_rule_matches_oracle_restatement():
+    cases = ["Hello world \U0001F60A", "Hi \U0001F642 there \U0001F621", "\U0001F60A ok \U0001F923", "(wow) \U0001F62E", "\U0001F914", "plain",
+             "\U0001F62D\U0001F60D both"]
+    for c in cases:
+        assert emoji.parse_response(c) == O.parse_emoji_response(c, emoji.is_emoji, emoji.replace_emoji)
+    assert emoji.EMOJI_MAPPING == O.EMOJI_MAPPING and len(emoji.EMOJI_MAPPING) == 11
+    assert emoji.parse_response("Hello world \U0001F60A") == ("Hello world ", 0)       # config 1: unmapped emoji -> speaker 0
+    assert emoji.first_contained_emoji_spk("sad \U0001F62D then \U0001F60D") == 107      # mapping order, not text order
+    assert emoji.first_contained_emoji_spk("no emoji") == 12
+
+
+def test_text_encoder_host_stage_matches_oracle(matcha_sd, golden):
+    from emojivoice_amd.text_encoder import TextEncoder, generate_path, sequence_mask
+
+    ids, xl = torch.from_numpy(golden["g3_ids"]), torch.from_numpy(golden["g3_x_lengths"])
+    spk = matcha_sd["spk_emb.weight"][torch.from_numpy(golden["g3_spks"])]
+    mu, logw, mask = TextEncoder(matcha_sd)(ids, xl, spk)
+    assert float((mu - torch.from_numpy(golden["g3_mu_x"])).abs().max()) <= 2e-5
+    assert float((logw - torch.from_numpy(golden["g3_logw"])).abs().max()) <= 2e-5
+    dur = torch.tensor([[2.0, 0.0, 3.0, 1.0]])
+    m = (sequence_mask(torch.tensor([4]), 4).unsqueeze(-1) * sequence_mask(torch.tensor([6]), 8).unsqueeze(1)).float()
+    assert torch.equal(generate_path(dur, m), O.generate_path(dur, m))
+
+
+def test_shard_bounds_cover_batch():
+    from emojivoice_amd.dist import shard_bounds
+
+    for n in (1, 7, 64, 512, 513):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_estimator_tensor_export(matcha_sd):
+    from emojivoice_amd.matcha_tts import estimator_tensors
+
+    t = estimator_tensors(matcha_sd)
+    assert "time_mlp.linear_1.weight" in t and "down_blocks.0.1.0.ff.net.0.alpha_exp" in t
+    a = matcha_sd["decoder.estimator.mid_blocks.1.1.0.ff.net.0.beta"]
+    assert torch.equal(t["mid_blocks.1.1.0.ff.net.0.beta_inv"], 1.0 / (torch.exp(a) + 1e-9))
+    assert sum(v.numel() for k, v in t.items() if not k.endswith(("_exp", "_inv"))) == 11139920
