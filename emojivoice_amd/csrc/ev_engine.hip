@@ -6,6 +6,7 @@
 #include "../../include/emojivoice.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -31,7 +32,8 @@ struct Geom { int nrows, S, P, T; };  // flattened padded time axis of one resol
 struct ConvLayer {
     float* W = nullptr;       // [ntaps][Mpad][Kpad]
     float* bias = nullptr;    // [Cout] (stacked / phase-replicated as needed) or null
-    uint32_t* tapmask[3] = {nullptr, nullptr, nullptr};  // for BM = 128, 64, 32
+    int2* taplist[3] = {nullptr, nullptr, nullptr};   // for BM = 128, 64, 32: [mtiles][EV_MAX_TAPS] {tap, row offset} (one shared row when dense)
+    int* nact[3] = {nullptr, nullptr, nullptr};       // per-tile active tap count (null when dense)
     bool sparse_taps = false;
     int ntaps = 0, off[EV_MAX_TAPS] = {0};
     int halo_lo = 0, halo_hi = 0;
@@ -45,7 +47,7 @@ struct Epi {
     int act2_lrelu = 0; float act2_slope = 0.f; int mask2 = 0; const float* rowmask = nullptr; int mmul = 1;
     float* Y2 = nullptr; int ldy2 = 0;
     float pro_slope = -1.f;                 // >= 0: prologue leaky-relu on the input
-    int dbg = 0; int force_cfg = -1;
+    int dbg = 0; int force_cfg = -1; int stagger = -1;
     int isplit_log2 = 31, isstride = 0;     // input column split (pair view of a strided slice)
     int osplit_log2 = 31, osstride = 0;     // output column split
 };
@@ -131,13 +133,14 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
         if (dev_upload(h, Wf, &L.W)) return 1;
     }
     if (bias) { if (dev_upload(h, *bias, &L.bias)) return 1; }
-    // per-tile non-zero tap masks
+    // per-tile compact lists of non-zero taps (polyphase transposed convs have all-zero (phase, tap) slabs)
     const int bms[3] = {128, 64, 32};
+    std::vector<std::vector<int2>> lists[3];
     L.sparse_taps = false;
     for (int k = 0; k < 3; ++k) {
         const int BM = bms[k];
         const int mt = L.Mpad / BM;
-        std::vector<uint32_t> mask(mt, 0u);
+        lists[k].resize(mt);
         for (int t = 0; t < mt; ++t)
             for (int tap = 0; tap < L.ntaps; ++tap) {
                 bool nz = false;
@@ -145,10 +148,27 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                     const float* row = &Wh[((size_t)tap * L.Mpad + m) * L.Kpad];
                     for (int c = 0; c < L.Kpad; ++c) if (row[c] != 0.f) { nz = true; break; }
                 }
-                if (nz) mask[t] |= 1u << tap;
+                if (nz) lists[k][t].push_back(make_int2(tap, L.off[tap]));
                 else if (t * BM < L.Cout) L.sparse_taps = true;
             }
-        if (dev_upload(h, mask, &L.tapmask[k])) return 1;
+    }
+    for (int k = 0; k < 3; ++k) {
+        const int mt = L.Mpad / bms[k];
+        if (!L.sparse_taps) {   // dense: one shared row holding every tap
+            std::vector<int2> row(EV_MAX_TAPS, make_int2(0, 0));
+            for (int tap = 0; tap < L.ntaps; ++tap) row[tap] = make_int2(tap, L.off[tap]);
+            if (dev_upload(h, row, &L.taplist[k])) return 1;
+            L.nact[k] = nullptr;
+        } else {
+            std::vector<int2> tab((size_t)mt * EV_MAX_TAPS, make_int2(0, 0));
+            std::vector<int> cnt(mt, 0);
+            for (int t = 0; t < mt; ++t) {
+                cnt[t] = (int)lists[k][t].size();
+                for (size_t i = 0; i < lists[k][t].size(); ++i) tab[(size_t)t * EV_MAX_TAPS + i] = lists[k][t][i];
+            }
+            if (dev_upload(h, tab, &L.taplist[k])) return 1;
+            if (dev_upload(h, cnt, &L.nact[k])) return 1;
+        }
     }
     return 0;
 }
@@ -259,11 +279,14 @@ int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** o
 // ---------------------------------------------------------------------------
 // launching
 // ---------------------------------------------------------------------------
+static int g_dbg_wgs_per_cu = 0;   // tools/conv_bench.py: cap workgroups per CU by over-allocating LDS (0 = off)
+
 template <int BM, int BN, int WM, int WN>
 void launch_cfg(const ConvParams& p, hipStream_t st) {
     // LDS holds the X tile during the K loop and, afterwards, one transposed 32-frame slab per wave for the epilogue
     constexpr size_t xs = (size_t)(BN + EV_HALO) * EV_LDK, es = (size_t)4 * 32 * (BM / WM + 4);
-    const size_t smem = (xs > es ? xs : es) * sizeof(float);
+    size_t smem = (xs > es ? xs : es) * sizeof(float);
+    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
@@ -289,9 +312,15 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     else if (L.Cout <= 64) cfg = 1;
     else {
         const long wgs128 = (long)(L.Mpad / 128) * ((g.nrows + 127) / 128);
-        cfg = (wgs128 >= 512 || L.Cout % 128 != 0) ? 0 : 1;
+        (void)wgs128;
+        cfg = 1;   // 64 x 128 tiles: measured >= the 128 x 128 tile on every HiFi-GAN / estimator shape (tools/conv_bench.py)
     }
-    if (e.force_cfg >= 0) cfg = e.force_cfg;
+    {   // debugging / test override: EV_FORCE_CFG=<0..3> forces one tile configuration for every conv launch
+        static const char* env = getenv("EV_FORCE_CFG");
+        if (env && *env) cfg = atoi(env);
+    }
+    g_dbg_wgs_per_cu = 0;
+    if (e.force_cfg >= 0) { cfg = e.force_cfg % 100; g_dbg_wgs_per_cu = e.force_cfg / 100; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         if (h->ev_used + 2 > h->ev_pool.size()) {
@@ -300,14 +329,22 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
+    {   // start stagger (see conv_gemm_kernel): only worth it when the grid is several rounds deep
+        const int slots = cfg == 0 ? 3 : (cfg == 1 ? 4 : 3);
+        const long wgs = cfg == 0 ? (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) : (cfg == 1 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) : (long)((L.Cout + 31) / 32) * ((g.nrows + 255) / 256));
+        p.stagger_slots = (wgs >= 256L * slots * 3) ? slots : 0;
+        if (e.stagger >= 0) p.stagger_slots = e.stagger;
+        static const char* senv = getenv("EV_STAGGER");
+        if (senv && *senv) p.stagger_slots = atoi(senv) ? p.stagger_slots : 0;
+    }
     if (cfg == 0) {
-        p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.tapmask = L.sparse_taps ? L.tapmask[0] : nullptr;
+        p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<128, 128, 2, 2>(p, h->stream);
     } else if (cfg == 1) {
-        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.tapmask = L.sparse_taps ? L.tapmask[1] : nullptr;
+        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 128, 2, 2>(p, h->stream);
     } else {
-        p.mtiles = (L.Cout + 31) / 32; p.ntiles = (g.nrows + 255) / 256; p.tapmask = L.sparse_taps ? L.tapmask[2] : nullptr;
+        p.mtiles = (L.Cout + 31) / 32; p.ntiles = (g.nrows + 255) / 256; p.taplist = L.taplist[2]; p.nact_tab = L.nact[2]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<32, 256, 1, 4>(p, h->stream);
     }
     HIPCHK(h, hipGetLastError());
@@ -878,6 +915,8 @@ int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* 
 // Kernel microbenchmark hook (tools/conv_bench.py): times `iters` launches of one resblock-style conv
 // (prologue lrelu, bias, residual) at a given geometry with HIP events; dbg = ablation bits, cfg = forced tile config.
 int ev_dbg_conv_bench(ev_handle* h, int Cin, int Cout, int K, int dil, int B, int T, int P, int iters, int dbg, int cfg, float* ms_out) {
+    const int stagger = (dbg & 64) ? 0 : -1;   // bit 64: disable the start stagger
+    dbg &= ~64;
     if (!h) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     h->stream = nullptr;
@@ -900,7 +939,7 @@ int ev_dbg_conv_bench(ev_handle* h, int Cin, int Cout, int K, int dil, int B, in
     for (auto& v : xh) { s = s * 1664525u + 1013904223u; v = (s >> 8) * (1.0f / 16777216.0f) - 0.5f; }
     for (size_t o = 0; o < nx; o += xh.size()) HIPCHK(h, hipMemcpy(X + o, xh.data(), std::min(xh.size(), nx - o) * 4, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(Y, 0, ny * 4));
-    Epi e; e.pro_slope = 0.1f; e.dbg = dbg; e.force_cfg = cfg;
+    Epi e; e.pro_slope = 0.1f; e.dbg = dbg; e.force_cfg = cfg; e.stagger = stagger;
     if (Cin == Cout) { e.R = X; e.ldr = Cin; }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));

@@ -21,6 +21,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define EV_MAX_TAPS 16
 #define EV_BK 32          // k (input-channel) chunk per LDS stage
@@ -42,7 +43,8 @@ struct ConvParams {
     int S, P, T;                            // store predicate: 0 <= (n % S) - P < T
     int ntaps; int off[EV_MAX_TAPS];
     int halo_lo, halo_hi;
-    const uint32_t* tapmask;                // per BM-row tile bitmask of non-zero taps, or null
+    const int2* taplist; int tl_stride;     // per M tile: compact list of non-zero taps {tap index, row offset}; stride 0 = shared
+    const int* nact_tab;                    // per M tile count of non-zero taps, or null (= ntaps)
     int mtiles, ntiles;
     float pro_slope; int pro_lrelu;         // prologue leaky-relu on X
     // epilogue (order: +bias, act, *mask1, *scale, +R, +Yold, /3, lrelu2, *mask2)
@@ -51,8 +53,30 @@ struct ConvParams {
     int act2_lrelu; float act2_slope; int mask2;
     const float* rowmask;
     float* Y2; int ldy2;                    // optional second output = v * rowmask
+    int stagger_slots;                      // workgroups co-resident per CU (0 = no start stagger), see conv_gemm_kernel
     int dbg;                                // ablation bits for tools/conv_bench.py: 1 skip X loads, 2 skip A loads, 4 skip epilogue
 };
+
+
+// Buffer (SRSRC) addressing for every global access of the conv kernels.  Measured on MI355X (tools/mfma_peak.hip):
+// flat `global_load_dwordx4` with per-lane 64-bit addresses issued by one wave costs the MFMA stream of the OTHER
+// waves on the same SIMD ~20 % (155 -> 120-125 TFLOP/s at 2-3 waves per SIMD); the same loads as `buffer_load_dwordx4`
+// (128-bit descriptor in SGPRs + one 32-bit per-lane byte offset) cost nothing.  All tensors here are < 4 GiB.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ev_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0xffffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ev_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+__device__ __forceinline__ float ev_bload1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff_bytes, (int)soff_bytes, 0));
+}
+__device__ __forceinline__ void ev_bstore4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff_bytes, 0, 0);
+}
+__device__ __forceinline__ void ev_bstore1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff_bytes, 0, 0);
+}
 
 __device__ __forceinline__ float ev_lrelu(float v, float s) { return v > 0.f ? v : v * s; }
 __device__ __forceinline__ float ev_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
@@ -77,6 +101,117 @@ __device__ __forceinline__ int ev_xcd_remap(int id, int nwg) {
     int q = nwg >> 3, r = nwg & 7, xcd = id & 7, within = id >> 3;
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + within;
+}
+
+// Fused conv epilogue for one wave's (TM*32 channels) x (TN*32 frames) accumulator tile whose first channel / frame are
+// mw0 / nw0.  Es = this wave's private LDS slab [32][TM*32 + 4].  Must be called by all waves of the workgroup
+// (it contains workgroup barriers).
+template <int TM, int TN>
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane) {
+    const int li = lane & 31, lh = lane >> 5;
+    // ---- epilogue.  C/D layout of the 32x32 tile: col = lane&31 (frame), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    // Each wave transposes one 32-frame slab of its tile through LDS into [frame][channel] so that the
+    // fused epilogue runs on whole float4 channel groups and stores 16 lanes x 16 B contiguous per frame.
+    constexpr int EC = TM * 32;          // channels of the wave's sub-tile
+    constexpr int ELD = EC + 4;          // LDS row stride
+    constexpr int C4 = EC / 4;           // float4 groups per frame
+    constexpr int RPP = 64 / C4;         // frames per pass of the wave
+    const bool vec_ok = ((p.ldy & 3) == 0) && ((p.Cout & 3) == 0) && ((p.osstride & 3) == 0) && (!p.R || (p.ldr & 3) == 0) &&
+                        (!p.Y2 || (p.ldy2 & 3) == 0);
+    const int omask = (p.osplit_log2 >= 31) ? 0x7fffffff : ((1 << p.osplit_log2) - 1);
+    const int er = lane / C4;            // frame within a pass
+    const int ec = (lane % C4) * 4;      // channel offset inside the sub-tile
+    const int co = mw0 + ec;
+    constexpr int NP = 32 / RPP;                 // passes per 32-frame slab
+    constexpr int NB = NP > 4 ? 4 : NP;          // passes whose residual / accumulate loads are in flight together
+    const bool co_ok = co < p.Cout;
+    const int sp = (p.osplit_log2 >= 31) ? 0 : (co >> p.osplit_log2);
+    const unsigned col = (unsigned)sp * p.osstride + (co & omask);   // column offset inside a row
+    const bool full = vec_ok && (co + 3 < p.Cout);
+    const __amdgpu_buffer_rsrc_t rY = ev_rsrc(p.Y), rR = ev_rsrc(p.R), rY2 = ev_rsrc(p.Y2);
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && co_ok) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[e] = p.bias[(co + e < p.Cout) ? co + e : p.Cout - 1];
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int pb = 0; pb < NP; pb += NB) {
+            // issue the global loads of this batch first: they fly while the slab is transposed through LDS
+            f32x4 rr[NB], yo[NB];
+            bool ok[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                const int n = nw0 + j * 32 + (pb + q) * RPP + er;
+                const int t = (n % p.S) - p.P;
+                ok[q] = co_ok && n < p.nrows && t >= 0 && t < p.T;
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                rr[q] = z; yo[q] = z;
+                if (ok[q]) {
+                    if (full) {
+                        if (p.R) rr[q] = ev_bload4(rR, ((unsigned)n * p.ldr + col) * 4u, 0);
+                        if (p.accum) yo[q] = ev_bload4(rY, ((unsigned)n * p.ldy + col) * 4u, 0);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (co + e < p.Cout) {
+                                if (p.R) rr[q][e] = ev_bload1(rR, ((unsigned)n * p.ldr + col + e) * 4u, 0);
+                                if (p.accum) yo[q][e] = ev_bload1(rY, ((unsigned)n * p.ldy + col + e) * 4u, 0);
+                            }
+                        }
+                    }
+                }
+            }
+            if (pb == 0) {
+                __syncthreads();             // LDS free (K loop done / previous slab consumed)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 q4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                        *(f32x4*)(Es + li * ELD + i * 32 + 8 * g + 4 * lh) = q4;
+                    }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int q = 0; q < NB; ++q) {
+                if (!ok[q]) continue;
+                const int rl = (pb + q) * RPP + er;
+                const int n = nw0 + j * 32 + rl;
+                const f32x4 a = *(const f32x4*)(Es + rl * ELD + ec);
+                float v[4] = {a[0], a[1], a[2], a[3]};
+                const float rm = p.rowmask ? p.rowmask[(size_t)n * p.mmul + sp] : 1.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = (co + e < p.Cout) ? co + e : p.Cout - 1;
+                    float x = v[e] + bs[e];
+                    if (p.act) x = ev_act(x, p.act, p.act_slope, p.act_a, p.act_b, c);
+                    if (p.mask1) x *= rm;
+                    x *= p.scale;
+                    if (p.R) x += rr[q][e];
+                    if (p.accum) x += yo[q][e];
+                    if (p.div3) x = x / 3.0f;
+                    if (p.act2_lrelu) x = ev_lrelu(x, p.act2_slope);
+                    if (p.mask2) x *= rm;
+                    v[e] = x;
+                }
+                if (full) {
+                    f32x4 o = {v[0], v[1], v[2], v[3]};
+                    ev_bstore4(rY, ((unsigned)n * p.ldy + col) * 4u, o);
+                    if (p.Y2) { f32x4 o2 = {v[0] * rm, v[1] * rm, v[2] * rm, v[3] * rm}; ev_bstore4(rY2, ((unsigned)n * p.ldy2 + col) * 4u, o2); }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (co + e < p.Cout) {
+                            ev_bstore1(rY, ((unsigned)n * p.ldy + col + e) * 4u, v[e]);
+                            if (p.Y2) ev_bstore1(rY2, ((unsigned)n * p.ldy2 + col + e) * 4u, v[e] * rm);
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N>
@@ -112,15 +247,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         if (dist >= BN || n0 + dist >= p.nrows) return;
     }
 
-    // active taps for this M tile: the idx-th set bit of the (wave-uniform) mask
-    uint32_t tmask = p.tapmask ? p.tapmask[mt] : 0xffffffffu;
-    tmask &= (p.ntaps >= 32) ? 0xffffffffu : ((1u << p.ntaps) - 1u);
-    const int nact = __builtin_popcount(tmask);
-    auto tap_at = [&](int idx) -> int {
-        uint32_t m = tmask;
-        for (int i = 0; i < idx; ++i) m &= m - 1u;  // drop the idx lowest set bits
-        return __builtin_ctz(m);
-    };
+    // active (non-zero) taps of this M tile: a host-built compact list read with scalar loads
+    const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
+    const int nact = p.nact_tab ? p.nact_tab[mt] : p.ntaps;
+
+    // Start stagger.  All tiles of a launch cost the same, so the workgroups that share a CU (dispatched together at
+    // t = 0) would otherwise stay in lockstep for the whole launch: every CU runs its MFMA phases at the same time and
+    // then its memory-bound epilogues at the same time.  Delaying the k-th co-resident workgroup of the FIRST wave of
+    // workgroups by k/slots of one tile time puts (and keeps) them out of phase: one streams its epilogue while the
+    // others feed the matrix pipe.
+    if (p.stagger_slots > 1 && (int)blockIdx.x < 256 * p.stagger_slots) {
+        const int slot = blockIdx.x >> 8;
+        const long tile_cycles = (long)(p.Kpad / EV_BK) * nact * (16L * TM * TN * 64) * p.stagger_slots;
+        const long wait = tile_cycles * slot / p.stagger_slots;
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(32);
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -143,18 +285,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     constexpr int XPASS = (BN + EV_HALO) / 32;
     const int mt32 = (m0 + wm * (TM * 32)) >> 5;          // first 32-row tile of this wave
     const int MT32 = p.Mpad >> 5, KG8 = p.Kpad >> 3;
-    const float* wlane = p.W + (size_t)lane * 4;
-    auto a_ptr = [&](int tap, int kg8) -> const float* {   // fragment of row-tile mt32 (+i) at absolute k-group kg8
-        return wlane + (((size_t)tap * MT32 + mt32) * KG8 + kg8) * 256;
+    const __amdgpu_buffer_rsrc_t rW = ev_rsrc(p.W), rX = ev_rsrc(p.X);
+    const unsigned wlane = (unsigned)lane * 16u;           // per-lane byte offset inside a 1 KiB fragment
+    auto a_off = [&](int tap, int kg8) -> unsigned {       // byte offset (wave-uniform) of row-tile mt32's fragment at k-group kg8
+        return (unsigned)(((tap * MT32 + mt32) * KG8 + kg8) * 1024);
     };
     // Two statically named fragment sets (A0/B0 for even k-groups, A1/B1 for odd ones): the loads for k-group g+1
     // are issued before the MFMAs of k-group g and first touched one k-group later — no register copies, so the
     // compiler's s_waitcnt lands at the first use and L2 / LDS latency hides under 16 MFMAs.
     f32x4 A0[TM], A1[TM], B0[TN], B1[TN];
-    auto ldA = [&](f32x4 (&dst)[TM], int tap, int kg8) {
-        const float* ap = a_ptr(tap, kg8);
+    auto ldAp = [&](f32x4 (&dst)[TM], unsigned aoff) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) dst[i] = *(const f32x4*)(ap + (size_t)i * KG8 * 256);
+        for (int i = 0; i < TM; ++i) dst[i] = ev_bload4(rW, wlane, aoff + (unsigned)(i * KG8 * 1024));
     };
     auto ldB = [&](f32x4 (&dst)[TN], const float* brow, int kg) {
 #pragma unroll
@@ -169,29 +311,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s4], b[j][s4], acc[i][j], 0, 0, 0);
     };
-    auto tap_off = [&](int tap) -> int {
-        int toff = 0;
-#pragma unroll
-        for (int q = 0; q < EV_MAX_TAPS; ++q) toff = (tap == q) ? p.off[q] : toff;   // static indexing keeps p in SGPRs
-        return toff;
-    };
     const float* bbase = Xs + (wn * (TN * 32) + li + p.halo_lo) * EV_LDK + 4 * lh;
-    const int tap_first = (nact > 0) ? tap_at(0) : 0;
-    if (nact > 0) ldA(A0, tap_first, 0);
+    const int2 tv_first = (nact > 0) ? tl[0] : make_int2(0, 0);
+    if (nact > 0) ldAp(A0, a_off(tv_first.x, 0));
     for (int ch = 0; ch < nchunks; ++ch) {
         __syncthreads();  // previous chunk's MFMAs are done with Xs
         {
             // ---- stage the X tile of this k-chunk (with the optional prologue leaky-relu): all loads first
             const int c = ch * EV_BK + sc4;
             const bool cok = c < p.Cin;
-            const float* xb = p.X + (size_t)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1));
+            const unsigned xcol = (unsigned)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1));
             f32x4 xv[XPASS];
 #pragma unroll
             for (int q = 0; q < XPASS; ++q) {
                 const int r = q * 32 + srow;
                 const int gr = n0 - p.halo_lo + r;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cok && r < xrows && gr >= 0 && gr < p.nrows) v = *(const f32x4*)(xb + (size_t)gr * p.ldx);
+                if (cok && r < xrows && gr >= 0 && gr < p.nrows && !(p.dbg & 1)) v = ev_bload4(rX, ((unsigned)gr * p.ldx + xcol) * 4u, 0);
                 xv[q] = v;
             }
 #pragma unroll
@@ -206,131 +342,44 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             }
         }
         __syncthreads();
-        int tap = tap_first;
-        const float* brow = bbase + tap_off(tap) * EV_LDK;
+        int tap = tv_first.x;
+        const float* brow = bbase + tv_first.y * EV_LDK;
         ldB(B0, brow, 0);
+        int2 tv_pre = tl[nact > 1 ? 1 : 0];            // tap list entries are fetched one tap ahead of their use
         for (int ti = 0; ti < nact; ++ti) {
             const bool last_tap = (ti + 1 == nact);
-            const int ntap = last_tap ? tap_first : tap_at(ti + 1);
-            const float* nbrow = bbase + tap_off(ntap) * EV_LDK;
-            const int kg8 = ch * 4;
-            ldA(A1, tap, kg8 + 1); ldB(B1, brow, 1);
+            const int2 ntv = last_tap ? tv_first : tv_pre;
+            tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
+            const int ntap = ntv.x;
+            const float* nbrow = bbase + ntv.y * EV_LDK;
+            const unsigned ap = a_off(tap, ch * 4);                                // k-groups of this tap: +1 KiB each
+            const unsigned nap = a_off(ntap, last_tap ? ch * 4 + 4 : ch * 4);
+            const bool have_next = !(last_tap && ch + 1 == nchunks);
+            // sched_barrier pins "loads of k-group g+1, then the 16 MFMAs of k-group g": hipcc otherwise sinks the
+            // prefetches into the MFMA block and waits for them a few MFMAs later
+            ldAp(A1, ap + 1024u); ldB(B1, brow, 1);
+            __builtin_amdgcn_sched_barrier(0);
             mma(A0, B0);
-            ldA(A0, tap, kg8 + 2); ldB(B0, brow, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A0, ap + 2048u); ldB(B0, brow, 2);
+            __builtin_amdgcn_sched_barrier(0);
             mma(A1, B1);
-            ldA(A1, tap, kg8 + 3); ldB(B1, brow, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A1, ap + 3072u); ldB(B1, brow, 3);
+            __builtin_amdgcn_sched_barrier(0);
             mma(A0, B0);
-            if (!last_tap) { ldA(A0, ntap, kg8); ldB(B0, nbrow, 0); }
-            else if (ch + 1 < nchunks) ldA(A0, ntap, kg8 + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            if (have_next) ldAp(A0, nap);
+            if (!last_tap) ldB(B0, nbrow, 0);
+            __builtin_amdgcn_sched_barrier(0);
             mma(A1, B1);
+            __builtin_amdgcn_sched_barrier(0);
             tap = ntap; brow = nbrow;
         }
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 tile: col = lane&31 (frame), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    // Each wave transposes one 32-frame slab of its tile through LDS into [frame][channel] so that the
-    // fused epilogue runs on whole float4 channel groups and stores 16 lanes x 16 B contiguous per frame.
     if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
-    constexpr int EC = TM * 32;          // channels of the wave's sub-tile
-    constexpr int ELD = EC + 4;          // LDS row stride
-    constexpr int C4 = EC / 4;           // float4 groups per frame
-    constexpr int RPP = 64 / C4;         // frames per pass of the wave
-    float* Es = smem + wave * (32 * ELD);
-    const bool vec_ok = ((p.ldy & 3) == 0) && ((p.Cout & 3) == 0) && ((p.osstride & 3) == 0) && (!p.R || (p.ldr & 3) == 0) &&
-                        (!p.Y2 || (p.ldy2 & 3) == 0);
-    const int omask = (p.osplit_log2 >= 31) ? 0x7fffffff : ((1 << p.osplit_log2) - 1);
-    const int er = lane / C4;            // frame within a pass
-    const int ec = (lane % C4) * 4;      // channel offset inside the sub-tile
-    const int co = m0 + wm * EC + ec;
-    constexpr int NP = 32 / RPP;                 // passes per 32-frame slab
-    constexpr int NB = NP > 4 ? 4 : NP;          // passes whose residual / accumulate loads are in flight together
-    const bool co_ok = co < p.Cout;
-    const int sp = (p.osplit_log2 >= 31) ? 0 : (co >> p.osplit_log2);
-    const size_t col = (size_t)sp * p.osstride + (co & omask);   // column offset inside a row
-    const bool full = vec_ok && (co + 3 < p.Cout);
-    float bs[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && co_ok) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bs[e] = p.bias[(co + e < p.Cout) ? co + e : p.Cout - 1];
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-#pragma unroll
-        for (int pb = 0; pb < NP; pb += NB) {
-            // issue the global loads of this batch first: they fly while the slab is transposed through LDS
-            f32x4 rr[NB], yo[NB];
-            bool ok[NB];
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                const int n = n0 + wn * (TN * 32) + j * 32 + (pb + q) * RPP + er;
-                const int t = (n % p.S) - p.P;
-                ok[q] = co_ok && n < p.nrows && t >= 0 && t < p.T;
-                f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                rr[q] = z; yo[q] = z;
-                if (ok[q]) {
-                    if (full) {
-                        if (p.R) rr[q] = *(const f32x4*)(p.R + (size_t)n * p.ldr + col);
-                        if (p.accum) yo[q] = *(const f32x4*)(p.Y + (size_t)n * p.ldy + col);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            if (co + e < p.Cout) {
-                                if (p.R) rr[q][e] = p.R[(size_t)n * p.ldr + col + e];
-                                if (p.accum) yo[q][e] = p.Y[(size_t)n * p.ldy + col + e];
-                            }
-                        }
-                    }
-                }
-            }
-            if (pb == 0) {
-                __syncthreads();             // LDS free (K loop done / previous slab consumed)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 q4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                        *(f32x4*)(Es + li * ELD + i * 32 + 8 * g + 4 * lh) = q4;
-                    }
-                __syncthreads();
-            }
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                if (!ok[q]) continue;
-                const int rl = (pb + q) * RPP + er;
-                const int n = n0 + wn * (TN * 32) + j * 32 + rl;
-                const f32x4 a = *(const f32x4*)(Es + rl * ELD + ec);
-                float v[4] = {a[0], a[1], a[2], a[3]};
-                const float rm = p.rowmask ? p.rowmask[(size_t)n * p.mmul + sp] : 1.f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = (co + e < p.Cout) ? co + e : p.Cout - 1;
-                    float x = v[e] + bs[e];
-                    if (p.act) x = ev_act(x, p.act, p.act_slope, p.act_a, p.act_b, c);
-                    if (p.mask1) x *= rm;
-                    x *= p.scale;
-                    if (p.R) x += rr[q][e];
-                    if (p.accum) x += yo[q][e];
-                    if (p.div3) x = x / 3.0f;
-                    if (p.act2_lrelu) x = ev_lrelu(x, p.act2_slope);
-                    if (p.mask2) x *= rm;
-                    v[e] = x;
-                }
-                if (full) {
-                    f32x4 o = {v[0], v[1], v[2], v[3]};
-                    *(f32x4*)(p.Y + (size_t)n * p.ldy + col) = o;
-                    if (p.Y2) { f32x4 o2 = {v[0] * rm, v[1] * rm, v[2] * rm, v[3] * rm}; *(f32x4*)(p.Y2 + (size_t)n * p.ldy2 + col) = o2; }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (co + e < p.Cout) {
-                            p.Y[(size_t)n * p.ldy + col + e] = v[e];
-                            if (p.Y2) p.Y2[(size_t)n * p.ldy2 + col + e] = v[e] * rm;
-                        }
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<TM, TN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
 // ---------------------------------------------------------------------------
