@@ -86,6 +86,7 @@ struct ev_handle {
     int ws_B = -1, ws_Tp = -1, ws_Tv = -1;
     // profiling
     bool prof = false;
+    bool fuse_pairs = true;     // EV_FUSE_PAIRS=0 disables resblock_pair_kernel (A/B runs)
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     double prof_flops = 0; int64_t prof_launches = 0;
     hipStream_t stream = nullptr;
@@ -357,6 +358,55 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     return 0;
 }
 
+// One fused ResBlock1 pair  y = c2(lrelu(c1(lrelu(x)))) + x  (resblock_pair_kernel) for C = 32 / 64.
+int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const float* X, float* Y, int C, const Geom& g, const Epi& e) {
+    PairParams pp;
+    memset(&pp, 0, sizeof pp);
+    ConvParams& p = pp.c2;
+    p.X = X; p.ldx = C; p.Cin = C; p.isplit_log2 = 31;
+    p.W = L2.W; p.Mpad = L2.Mpad; p.Kpad = L2.Kpad; p.bias = L2.bias;
+    p.Y = Y; p.ldy = C; p.Cout = C; p.osplit_log2 = 31; p.mmul = 1;
+    p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T;
+    p.ntaps = L2.ntaps; p.taplist = L2.taplist[0]; p.tl_stride = 0; p.nact_tab = nullptr;
+    p.pro_lrelu = 1; p.pro_slope = 0.1f;
+    p.scale = 1.f; p.R = X; p.ldr = C; p.accum = e.accum; p.div3 = e.div3; p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope;
+    pp.W1 = L1.W; pp.b1 = L1.bias; pp.taplist1 = L1.taplist[0]; pp.ntaps1 = L1.ntaps;
+    pp.h1 = L1.halo_lo; pp.h2 = L2.halo_lo; pp.mid_slope = 0.1f;
+    if (L1.sparse_taps || L2.sparse_taps || L1.Kpad != C || L2.Kpad != C || L1.Kpad != L2.Kpad || L1.Mpad != L2.Mpad || L1.halo_lo != L1.halo_hi ||
+        L2.halo_lo != L2.halo_hi || 2 * pp.h2 > 16 || !L1.bias || !L2.bias)
+        return fail(h, "launch_pair: unsupported layer pair");
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t ev; HIPCHK(h, hipEventCreate(&ev)); h->ev_pool.push_back(ev); }
+        }
+        e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+    }
+    if (C == 32) {
+        constexpr int NT = 256;
+        pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
+        const size_t smem = (size_t)(NT + EV_HALO) * EV_LDK * sizeof(float);
+        hipLaunchKernelGGL((resblock_pair_kernel<1, 4>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+    } else if (C == 64) {
+        constexpr int NT = 128;
+        pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
+        const size_t xs = (size_t)(NT + EV_HALO) * EV_LDK, ys = (size_t)2 * (NT + 16) * EV_LDK;
+        const size_t smem = (xs > ys ? xs : ys) * sizeof(float);
+        hipLaunchKernelGGL((resblock_pair_kernel<2, 2>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+    } else {
+        return fail(h, "launch_pair: C must be 32 or 64");
+    }
+    HIPCHK(h, hipGetLastError());
+    if (h->prof) {
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        const double valid_rows = (double)(g.nrows / g.S) * g.T;
+        h->prof_flops += 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows;
+        h->prof_launches += 1;
+    }
+    return 0;
+}
+
 int launch_gn(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const float* gamma, const float* beta, const float* rowmask,
               const float* temb, const float* R, int ldr, const Geom& g, int C, int mode) {
     GNParams p;
@@ -618,6 +668,7 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     ev_handle* h = new ev_handle();
     h->device = device;
     h->dims = *dims;
+    { const char* fp = getenv("EV_FUSE_PAIRS"); if (fp && *fp == '0') h->fuse_pairs = false; }
     if (dims->n_feats != 80 || dims->channels != 256 || dims->head_dim != 64 || dims->heads < 1 || dims->heads > 8) {
         delete h;
         return 4;
@@ -863,8 +914,6 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
             const float* x = v.U[l];
             float* pp[2] = {v.Pa[l], v.Pb[l]};
             for (int mm = 0; mm < 3; ++mm) {
-                Epi e1; e1.pro_slope = 0.1f; e1.act = ACT_LRELU; e1.act_slope = 0.1f;   // lrelu -> c1 -> lrelu
-                if (launch_conv(h, w.c1[i * 3 + j][mm], x, C, v.T1[l], C, v.g[l], e1)) return 1;
                 Epi e2; e2.R = x; e2.ldr = C;                                          // c2 + x
                 float* y = pp[mm & 1];
                 if (mm == 2) {   // resblock output joins the running mean over the 3 kernel sizes (models.py:186-192)
@@ -872,7 +921,14 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
                     e2.accum = (j > 0);
                     if (j == 2) { e2.div3 = 1; e2.act2_lrelu = 1; e2.act2_slope = (i == 3) ? 0.01f : 0.1f; }  // next consumer's leaky_relu
                 }
-                if (launch_conv(h, w.c2[i * 3 + j][mm], v.T1[l], C, y, C, v.g[l], e2)) return 1;
+                if (h->fuse_pairs && (C == 32 || C == 64)) {
+                    // narrow stages: both convs of the pair in one launch, intermediate kept in LDS
+                    if (launch_pair(h, w.c1[i * 3 + j][mm], w.c2[i * 3 + j][mm], x, y, C, v.g[l], e2)) return 1;
+                } else {
+                    Epi e1; e1.pro_slope = 0.1f; e1.act = ACT_LRELU; e1.act_slope = 0.1f;   // lrelu -> c1 -> lrelu
+                    if (launch_conv(h, w.c1[i * 3 + j][mm], x, C, v.T1[l], C, v.g[l], e1)) return 1;
+                    if (launch_conv(h, w.c2[i * 3 + j][mm], v.T1[l], C, y, C, v.g[l], e2)) return 1;
+                }
                 x = y;
             }
         }

@@ -107,7 +107,8 @@ __device__ __forceinline__ int ev_xcd_remap(int id, int nwg) {
 // mw0 / nw0.  Es = this wave's private LDS slab [32][TM*32 + 4].  Must be called by all waves of the workgroup
 // (it contains workgroup barriers).
 template <int TM, int TN>
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane) {
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane,
+                                              int win_lo = -0x7fffffff, int win_hi = 0x7fffffff) {
     const int li = lane & 31, lh = lane >> 5;
     // ---- epilogue.  C/D layout of the 32x32 tile: col = lane&31 (frame), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     // Each wave transposes one 32-frame slab of its tile through LDS into [frame][channel] so that the
@@ -145,7 +146,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             for (int q = 0; q < NB; ++q) {
                 const int n = nw0 + j * 32 + (pb + q) * RPP + er;
                 const int t = (n % p.S) - p.P;
-                ok[q] = co_ok && n < p.nrows && t >= 0 && t < p.T;
+                ok[q] = co_ok && n < p.nrows && t >= 0 && t < p.T && n >= win_lo && n < win_hi;
                 f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 rr[q] = z; yo[q] = z;
                 if (ok[q]) {
@@ -380,6 +381,187 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 
     if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
     conv_epilogue<TM, TN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+// ---------------------------------------------------------------------------
+// resblock_pair_kernel: one (c1, c2) pair of HiFi-GAN ResBlock1 (hifigan/models.py:90-97) in ONE launch:
+//     x' = c2( lrelu( c1( lrelu(x) ) + b1 ) ) + b2 + x          c1: k taps, dilation d;  c2: k taps, dilation 1
+// for the narrow stages (C = 32 / 64), where a single conv is HBM-coupled (16-37 FLOP/B: one activation read,
+// one residual read and one write per 2*C*C*k FLOP).  The intermediate lrelu(c1(.)) tile never leaves the CU: it
+// is written to LDS in the [frame][channel] operand layout and consumed by the second MFMA loop, so a pair costs
+// one read of x (+ an L2-hot re-read of the tile for the residual) and one write of x' — 2.5x less HBM traffic, half
+// the launches and twice the matrix work per memory phase.
+//   compute rows r in [0, NT): global row g0 + r, g0 = n0 - h2;  c1 is evaluated on all NT rows, c2's outputs are
+//   valid for r in [h2, NT - h2) = global [n0, n0 + NT - 2*h2) (tiles overlap by the c2 halo).  y1 rows outside the
+//   utterance are zeroed: they are c2's zero padding.
+// ---------------------------------------------------------------------------
+struct PairParams {
+    ConvParams c2;                 // c2 + epilogue view: X = x (input), W/bias/taplist = c2's, R = x, Y = output, flags
+    const float* W1; const float* b1; const int2* taplist1; int ntaps1;
+    int h1, h2;                    // halos of c1 (dilated) and c2
+    float mid_slope;               // leaky-relu slope between the convs
+    int out_rows;                  // NT - 2*h2
+};
+
+template <int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp) {
+    constexpr int TM = 1, TN = 2;
+    constexpr int NT = WAVES_N * TN * 32;               // compute rows per workgroup
+    constexpr int NCH = WAVES_M;                        // 32-channel chunks (C = 32 * WAVES_M)
+    constexpr int XROWS = NT + EV_HALO;
+    constexpr int YROWS = NT + 16;                      // + 2*h2 (<= 10) rounded up
+    constexpr int XPASS = XROWS / 32;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    const ConvParams& p = pp.c2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                   // phase 1: [XROWS][EV_LDK]
+    float* Ys = smem;                                   // phase 2 (aliases Xs): [NCH][YROWS][EV_LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+    const int srow = tid >> 3, sc4 = (tid & 7) * 4;
+
+    const int nt = ev_xcd_remap(blockIdx.x, p.ntiles);
+    const int n0 = nt * pp.out_rows;                    // first output row of this tile
+    const int g0 = n0 - pp.h2;                          // global row of compute row 0
+    {   // tiles whose output window holds no storable row do nothing
+        const int s0 = n0 % p.S, t_first = s0 - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - s0 + p.P;
+        if (dist >= pp.out_rows || n0 + dist >= p.nrows) return;
+    }
+
+    const int MT32 = p.Mpad >> 5, KG8 = p.Kpad >> 3;
+    const unsigned wlane = (unsigned)lane * 16u;
+    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(p.X);
+    f32x16 acc[TM][TN];
+    f32x4 A0[TM], A1[TM], B0[TN], B1[TN];
+
+    // one conv phase: K loop over NCH chunks x taps with the A/B fragment pipeline of conv_gemm_kernel
+    auto phase = [&](const float* Wf, const int2* tl, int nact, auto&& chunk_base) {
+        const __amdgpu_buffer_rsrc_t rW = ev_rsrc(Wf);
+        auto a_off = [&](int tap, int kg8) -> unsigned { return (unsigned)(((tap * MT32 + wm) * KG8 + kg8) * 1024); };
+        auto ldAp = [&](f32x4 (&dst)[TM], unsigned aoff) { dst[0] = ev_bload4(rW, wlane, aoff); };
+        auto ldB = [&](f32x4 (&dst)[TN], const float* brow, int kg) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dst[j] = *(const f32x4*)(brow + j * 32 * EV_LDK + kg * 8);
+        };
+        auto mma = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s4], b[j][s4], acc[0][j], 0, 0, 0);
+        };
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+        const int2 tv_first = tl[0];
+        ldAp(A0, a_off(tv_first.x, 0));
+        for (int ch = 0; ch < NCH; ++ch) {
+            const float* bbase = chunk_base(ch);        // LDS row 0 of this chunk for this lane (stages + barriers inside)
+            int tap = tv_first.x;
+            const float* brow = bbase + tv_first.y * EV_LDK;
+            ldB(B0, brow, 0);
+            int2 tv_pre = tl[nact > 1 ? 1 : 0];
+            for (int ti = 0; ti < nact; ++ti) {
+                const bool last_tap = (ti + 1 == nact);
+                const int2 ntv = last_tap ? tv_first : tv_pre;
+                tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
+                const float* nbrow = bbase + ntv.y * EV_LDK;
+                const unsigned ap = a_off(tap, ch * 4);
+                const unsigned nap = a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4);
+                const bool have_next = !(last_tap && ch + 1 == NCH);
+                ldAp(A1, ap + 1024u); ldB(B1, brow, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(A0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                ldAp(A0, ap + 2048u); ldB(B0, brow, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(A1, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                ldAp(A1, ap + 3072u); ldB(B1, brow, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(A0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (have_next) ldAp(A0, nap);
+                if (!last_tap) ldB(B0, nbrow, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(A1, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                tap = ntv.x; brow = nbrow;
+            }
+        }
+    };
+
+    // ---------------- phase 1: c1 over lrelu(x), X tile rows [g0 - h1, g0 + NT + h1) staged per 32-channel chunk
+    const int xrows = NT + 2 * pp.h1;
+    phase(pp.W1, pp.taplist1, pp.ntaps1, [&](int ch) -> const float* {
+        __syncthreads();
+        const int c = ch * EV_BK + sc4;
+        f32x4 xv[XPASS];
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) {
+            const int r = q * 32 + srow;
+            const int gr = g0 - pp.h1 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (r < xrows && gr >= 0 && gr < p.nrows) v = ev_bload4(rX, ((unsigned)gr * p.ldx + c) * 4u, 0);
+            xv[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) {
+            const int r = q * 32 + srow;
+            f32x4 v = xv[q];
+            v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+            v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+            if (r < xrows) *(f32x4*)(Xs + r * EV_LDK + sc4) = v;
+        }
+        __syncthreads();
+        return Xs + (wn * (TN * 32) + li + pp.h1) * EV_LDK + 4 * lh;
+    });
+
+    // ---------------- y1 = lrelu(c1 + b1), zero outside the utterance, into LDS [chunk = wm][row + h2][channel]
+    __syncthreads();                                    // every wave is done reading Xs
+    {
+        f32x4 b1v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(pp.b1 + wm * 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * (TN * 32) + j * 32 + li;
+            const int n = g0 + r;
+            const int t = (n >= 0 && n < p.nrows) ? (n % p.S) - p.P : -1;
+            const bool inside = t >= 0 && t < p.T;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = inside ? ev_lrelu(acc[0][j][4 * g + e] + b1v[g][e], pp.mid_slope) : 0.f;
+                *(f32x4*)(Ys + (wm * YROWS + r + pp.h2) * EV_LDK + 8 * g + 4 * lh) = v;
+            }
+        }
+        // the 2*h2 border rows only feed outputs outside the stored window, but must be finite
+        if (tid < 2 * pp.h2 * 8 * NCH) {
+            const int chn = tid / (2 * pp.h2 * 8), rem = tid % (2 * pp.h2 * 8);
+            const int br = rem / 8, c4 = (rem % 8) * 4;
+            const int row = br < pp.h2 ? br : NT + br;   // rows [0,h2) and [NT+h2, NT+2*h2)
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(Ys + (chn * YROWS + row) * EV_LDK + c4) = z;
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 2: c2 over the LDS-resident y1 (tap i reads rows r + i)
+    phase(p.W, p.taplist, p.ntaps, [&](int ch) -> const float* {
+        return Ys + (ch * YROWS + wn * (TN * 32) + li + pp.h2) * EV_LDK + 4 * lh;
+    });
+
+    // ---------------- epilogue: + b2 + x (residual re-read, L2-hot), optional running resblock mean, window [n0, n0 + out_rows)
+    conv_epilogue<TM, TN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
 }
 
 // ---------------------------------------------------------------------------
