@@ -142,3 +142,33 @@ def test_fails_loudly_without_gpu_path():
 
     with pytest.raises(EvLibraryError):
         Generator(AttrDict(v1)).to("cpu")
+
+
+def test_denoiser_vs_golden(golden, vocoder):
+    """device-side Denoiser (bias spectrum from the HIP vocoder on a zero mel) vs the reference's."""
+    from emojivoice_amd.denoiser import Denoiser
+
+    den = Denoiser(vocoder, mode="zeros")
+    ref_bias = golden["g7_bias_spec"]
+    assert _linf(den.bias_spec, ref_bias) <= 1e-3 * max(1.0, float(np.abs(ref_bias).max()))
+    audio = T_(golden["g4_wav"]).clamp(-1, 1).squeeze().cuda()
+    d = den(audio, strength=0.00025)
+    assert tuple(d.shape) == golden["g7_denoised"].shape        # length stays 256*T, (B, L)
+    assert _linf(d, golden["g7_denoised"]) <= 1e-4
+
+
+def test_cli_writes_pcm24_wav(tmp_path):
+    """Config 1 plumbing: ids + an unmapped emoji (-> speaker 0) -> 22.05 kHz PCM_24 wav, wav_len == 256 * mel_len."""
+    import wave
+
+    from emojivoice_amd import cli
+
+    ids = " ".join(str(i) for i in [23, 51, 7, 99, 140, 31, 12, 64, 8, 77, 101, 5])
+    cli.cli(["--synthetic", "--ids", ids, "--add_blank", "--emoji-text", "Hello world \U0001F60A", "--steps", "10",
+             "--output_folder", str(tmp_path)])
+    wavs = sorted(tmp_path.glob("*.wav"))
+    assert len(wavs) == 1 and "speaker_000" in wavs[0].name
+    mel = np.load(str(wavs[0])[:-4] + ".npy")
+    with wave.open(str(wavs[0])) as w:
+        assert (w.getframerate(), w.getsampwidth(), w.getnchannels()) == (22050, 3, 1)
+        assert w.getnframes() == 256 * mel.shape[1]
