@@ -170,10 +170,20 @@ def main():
             e.profile_enable(False)
         conv_ms, conv_fl, conv_n = ms_c + ms_v, fl_c + fl_v, n_c + n_v
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
+        # HBM bytes per conv launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note in MI355X_MICROARCH.md); not measurable live
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(REPO, "profiles", "r01_conv_hbm_traffic_pmc.json")))
+            if B == 64 and T == 516 and n_ode == 10:
+                traffic = {"bytes_per_launch": round(tj["hbm_MB_per_launch"] * 1e6), "GB_per_step": round(tj["hbm_GB_per_step"], 1),
+                           "source": "profiles/r01_conv_hbm_traffic_pmc.json"}
+        except Exception:
+            pass
         per_gpu = value / world
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                    "kernel": "conv_gemm_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "kernel": "conv_gemm_kernel + resblock_pair_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
                     "launches_per_step": int(conv_n), "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
                     "alg_gflop_per_launch": round(conv_fl / max(conv_n, 1) / 1e9, 3),
                     "conv_ms_per_step": round(conv_ms, 2), "conv_ms_cfm": round(ms_c, 2), "conv_ms_hifigan": round(ms_v, 2),

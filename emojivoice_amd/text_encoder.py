@@ -64,7 +64,19 @@ class TextEncoder:
 
     def _conv(self, name: str, x: Tensor) -> Tensor:
         w = self.sd[f"{name}.weight"]
-        return F.conv1d(x, w, self.sd[f"{name}.bias"], padding=w.shape[2] // 2)
+        b = self.sd[f"{name}.bias"]
+        k = w.shape[2]
+        if not x.is_cuda:
+            return F.conv1d(x, w, b, padding=k // 2)
+        # On the GPU a "same" Conv1d is evaluated as k shifted GEMMs (rocBLAS): MIOpen's conv1d searches / compiles a
+        # solver for every new (B, L), which costs 50-500 ms the first time a streaming caller sees a text length.
+        if k == 1:
+            return torch.matmul(w[:, :, 0], x) + b[:, None]
+        xp = F.pad(x, (k // 2, k // 2))
+        L = x.shape[-1]
+        cols = torch.cat([xp[:, :, i:i + L] for i in range(k)], dim=1)          # (B, k*Cin, L), tap-major
+        wk = w.permute(0, 2, 1).reshape(w.shape[0], -1)                         # (Cout, k*Cin)
+        return torch.matmul(wk, cols) + b[:, None]
 
     def _attn(self, name: str, x: Tensor, attn_mask: Tensor) -> Tensor:
         q, k, v = (self._conv(f"{name}.conv_{n}", x) for n in "qkv")
