@@ -96,3 +96,41 @@ def test_estimator_tensor_export(matcha_sd):
     a = matcha_sd["decoder.estimator.mid_blocks.1.1.0.ff.net.0.beta"]
     assert torch.equal(t["mid_blocks.1.1.0.ff.net.0.beta_inv"], 1.0 / (torch.exp(a) + 1e-9))
     assert sum(v.numel() for k, v in t.items() if not k.endswith(("_exp", "_inv"))) == 11139920
+
+
+class _FakeDictConfig(dict):
+    """Stands in for omegaconf.DictConfig inside a Lightning checkpoint's hyper_parameters."""
+
+
+def test_checkpoint_reader_stubs_foreign_classes(tmp_path, matcha_sd):
+    """cli.py:110-118: real .ckpt files pickle omegaconf / functools.partial(optimizer) objects in ``hyper_parameters``;
+    the reader must get the tensors out without importing them."""
+    import functools
+
+    from emojivoice_amd.matcha_tts import _load_ckpt
+
+    small = {k: v for k, v in list(matcha_sd.items())[:6]}
+    ckpt = {"state_dict": small, "hyper_parameters": {"encoder": _FakeDictConfig(n_feats=80), "optimizer": functools.partial(_FakeDictConfig, lr=1e-4)},
+            "epoch": 3, "pytorch-lightning_version": "2.1.0"}
+    path = tmp_path / "fake.ckpt"
+    torch.save(ckpt, path)
+    got = _load_ckpt(str(path))
+    assert set(got["state_dict"]) == set(small)
+    for k in small:
+        assert torch.equal(got["state_dict"][k], small[k])
+
+
+def test_hifigan_state_dict_roundtrip(voc_sd):
+    """Generator.load_state_dict accepts the raw weight_g/weight_v form and the folded form, strictly."""
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+
+    g = Generator(AttrDict(v1))
+    g.load_state_dict(W.weight_norm_split(voc_sd))
+    g.remove_weight_norm()
+    sd = g.state_dict()
+    assert set(sd) == set(voc_sd)
+    assert max(float((sd[k] - voc_sd[k]).abs().max()) for k in voc_sd) <= 1e-6
+    bad = dict(voc_sd)
+    bad.pop("conv_post.bias")
+    with pytest.raises(RuntimeError):
+        Generator(AttrDict(v1)).load_state_dict(bad)

@@ -172,3 +172,38 @@ def test_cli_writes_pcm24_wav(tmp_path):
     with wave.open(str(wavs[0])) as w:
         assert (w.getframerate(), w.getsampwidth(), w.getnchannels()) == (22050, 3, 1)
         assert w.getnframes() == 256 * mel.shape[1]
+
+
+@pytest.mark.parametrize("B,Tp,lens,steps", [(1, 4, [3], 2), (2, 8, [8, 1], 3), (1, 1032, [1030], 2)])
+def test_cfm_edge_shapes(model, matcha_sd, B, Tp, lens, steps):
+    """Smallest legal Tp (4), a 1-frame utterance beside a full one, and a 12-s utterance (33 key tiles in attention)."""
+    g = torch.Generator().manual_seed(Tp + 7)
+    mu = torch.randn(B, 80, Tp, generator=g)
+    z = torch.randn(B, 80, Tp, generator=g)
+    lengths = torch.tensor(lens)
+    mask = O.sequence_mask(lengths, Tp).unsqueeze(1).float()
+    spk = matcha_sd["spk_emb.weight"][torch.tensor([17, 0][:B])]
+    ref = O.cfm_decode(matcha_sd, mu * mask, mask, steps, 1.0, spk, z=z)
+    dec, _ = model.decode((mu * mask).cuda(), lengths.cuda(), steps, 1.0, spk.cuda(), z=z.cuda())
+    assert _linf(dec, ref) <= MEL_GATE / 2
+
+
+def test_hifigan_single_frame(vocoder, voc_sd):
+    mel = torch.randn(1, 80, 1, generator=torch.Generator().manual_seed(3)) - 5.0
+    ref = O.hifigan_forward(voc_sd, mel, W.HIFIGAN_V1)
+    wav = vocoder(mel.cuda())
+    assert wav.shape == (1, 1, 256)
+    assert float((wav.cpu() - ref).pow(2).mean().sqrt()) <= WAV_RMS_GATE / 10
+
+
+def test_argument_errors(model):
+    from emojivoice_amd._lib import EvLibraryError
+
+    mu = torch.zeros(1, 80, 6).cuda()       # Tp not a multiple of 4 (fix_len_compatibility violated)
+    with pytest.raises(EvLibraryError):
+        model.engine.cfm_decode(mu, torch.tensor([6]).cuda(), torch.zeros(1, 64).cuda(), mu, 2)
+    mu = torch.zeros(1, 80, 8).cuda()
+    with pytest.raises(EvLibraryError):
+        model.engine.cfm_decode(mu, torch.tensor([8]).cuda(), torch.zeros(1, 64).cuda(), mu, 0)     # steps > 0 (cli.py:143)
+    with pytest.raises(AttributeError):   # spks required when n_spks > 1, same failure mode as matcha_tts.py:118
+        model.synthesise(torch.ones(1, 5, dtype=torch.long).cuda(), torch.tensor([5]).cuda(), 2, spks=None)
