@@ -156,14 +156,32 @@ class MatchaTTS:
 # ---------------------------------------------------------------------------
 # checkpoint reading without lightning / omegaconf
 # ---------------------------------------------------------------------------
-class _Stub:
+class _Stub(dict):
+    """Inert stand-in for any class the checkpoint pickles that is not a tensor container (omegaconf nodes,
+    functools.partial of an optimizer, lightning enums ...): accepts every way pickle builds or fills an object."""
+
     def __init__(self, *a, **k):
-        pass
+        super().__init__()
 
     def __call__(self, *a, **k):
         return self
 
     def __setstate__(self, s):
+        pass
+
+    def __reduce_ex__(self, protocol):
+        return (_Stub, ())
+
+    def append(self, *_):
+        pass
+
+    def extend(self, *_):
+        pass
+
+    def add(self, *_):
+        pass
+
+    def __setattr__(self, k, v):
         pass
 
 
