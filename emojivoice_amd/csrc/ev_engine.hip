@@ -87,6 +87,7 @@ struct ev_handle {
     // profiling
     bool prof = false;
     bool fuse_pairs = true;     // EV_FUSE_PAIRS=0 disables resblock_pair_kernel (A/B runs)
+    int fuse128 = 3;            // fuse C=128 pairs up to this kernel size (EV_FUSE128=0/3/7/11)
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     double prof_flops = 0; int64_t prof_launches = 0;
     hipStream_t stream = nullptr;
@@ -282,13 +283,13 @@ int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** o
 // ---------------------------------------------------------------------------
 static int g_dbg_wgs_per_cu = 0;   // tools/conv_bench.py: cap workgroups per CU by over-allocating LDS (0 = off)
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PF = false>
 void launch_cfg(const ConvParams& p, hipStream_t st) {
     // LDS holds the X tile during the K loop and, afterwards, one transposed 32-frame slab per wave for the epilogue
     constexpr size_t xs = (size_t)(BN + EV_HALO) * EV_LDK, es = (size_t)4 * 32 * (BM / WM + 4);
     size_t smem = (xs > es ? xs : es) * sizeof(float);
-    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
 int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {
@@ -307,14 +308,27 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     p.Y2 = e.Y2; p.ldy2 = e.ldy2; p.dbg = e.dbg;
     if ((ldx & 3) || (L.Cin & 3)) return fail(h, "conv input must be float4-aligned (ldx %d Cin %d)", ldx, L.Cin);
 
-    // tile choice: BM by output width; fall back to smaller tiles when the grid would not fill 256 CUs twice
+    // Tile choice.  cfg: 0 = 128x128, 1 = 64x128, 2 = 32x256, 5 = 64x192, 6 = 64x64 (channels x frames per workgroup).
+    // A launch that fits the chip in about one round of workgroups is decided by its makespan: e.g. 1040 tiles on
+    // 1024 slots run 16 stragglers after everyone else (measured: the matrix pipes idle for half of such a launch), and
+    // 520 tiles on 256 CUs leave 8 CUs with three tiles.  So estimate, per candidate, the busiest CU's share of the
+    // MFMA work and take the minimum; deep grids (HiFi-GAN) keep the 64x128 tile measured best by tools/conv_bench.py.
     int cfg;
     if (L.Cout <= 32) cfg = 2;
-    else if (L.Cout <= 64) cfg = 1;
     else {
-        const long wgs128 = (long)(L.Mpad / 128) * ((g.nrows + 127) / 128);
-        (void)wgs128;
-        cfg = 1;   // 64 x 128 tiles: measured >= the 128 x 128 tile on every HiFi-GAN / estimator shape (tools/conv_bench.py)
+        struct Cand { int cfg, bm, bn, slots; };
+        const Cand cands[3] = {{1, 64, 128, 4}, {5, 64, 192, 4}, {6, 64, 64, 5}};
+        double best = 1e30;
+        cfg = 1;
+        for (const Cand& c : cands) {
+            const long nwg = (long)((L.Cout + c.bm - 1) / c.bm) * ((g.nrows + c.bn - 1) / c.bn);
+            const double w = (double)(c.bm / 32) * (c.bn / 32);           // MFMA tiles per workgroup
+            double t;
+            if (nwg <= 256L * c.slots) t = (double)((nwg + 255) / 256) * w;          // one round: the busiest CU
+            else t = (double)nwg * w / 256.0 + (nwg < 256L * c.slots * 3 ? w : 0.0);  // deep grid: balanced + a short tail
+            t *= (c.cfg == 6 ? 1.08 : 1.0);                               // small tiles re-read more operands
+            if (t < best - 1e-9) { best = t; cfg = c.cfg; }
+        }
     }
     {   // debugging / test override: EV_FORCE_CFG=<0..3> forces one tile configuration for every conv launch
         static const char* env = getenv("EV_FORCE_CFG");
@@ -331,8 +345,8 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
     {   // start stagger (see conv_gemm_kernel): only worth it when the grid is several rounds deep
-        const int slots = cfg == 0 ? 3 : (cfg == 1 ? 4 : 3);
-        const long wgs = cfg == 0 ? (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) : (cfg == 1 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) : (long)((L.Cout + 31) / 32) * ((g.nrows + 255) / 256));
+        const int slots = cfg == 0 ? 3 : ((cfg == 1 || cfg == 5) ? 4 : (cfg == 6 ? 5 : 3));
+        const long wgs = cfg == 5 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 191) / 192) : cfg == 6 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64) : cfg == 0 ? (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) : (cfg == 1 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) : (long)((L.Cout + 31) / 32) * ((g.nrows + 255) / 256));
         p.stagger_slots = (wgs >= 256L * slots * 3) ? slots : 0;
         if (e.stagger >= 0) p.stagger_slots = e.stagger;
         static const char* senv = getenv("EV_STAGGER");
@@ -344,6 +358,15 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     } else if (cfg == 1) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 128, 2, 2>(p, h->stream);
+    } else if (cfg == 5) {
+        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_cfg<64, 192, 2, 2>(p, h->stream);
+    } else if (cfg == 6) {
+        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_cfg<64, 64, 2, 2>(p, h->stream);
+    } else if (cfg == 4) {   // 64 x 128 tile with register-prefetched X staging (single-round launches)
+        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_cfg<64, 128, 2, 2, true>(p, h->stream);
     } else {
         p.mtiles = (L.Cout + 31) / 32; p.ntiles = (g.nrows + 255) / 256; p.taplist = L.taplist[2]; p.nact_tab = L.nact[2]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<32, 256, 1, 4>(p, h->stream);
@@ -394,8 +417,14 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         const size_t xs = (size_t)(NT + EV_HALO) * EV_LDK, ys = (size_t)2 * (NT + 16) * EV_LDK;
         const size_t smem = (xs > ys ? xs : ys) * sizeof(float);
         hipLaunchKernelGGL((resblock_pair_kernel<2, 2>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+    } else if (C == 128) {
+        constexpr int NT = 64;    // 4 waves = 4 channel tiles; 64 compute rows keep the 128-channel intermediate in 46 KB of LDS
+        pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
+        const size_t xs = (size_t)(NT + EV_HALO) * EV_LDK, ys = (size_t)4 * (NT + 16) * EV_LDK;
+        const size_t smem = (xs > ys ? xs : ys) * sizeof(float);
+        hipLaunchKernelGGL((resblock_pair_kernel<4, 1>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
     } else {
-        return fail(h, "launch_pair: C must be 32 or 64");
+        return fail(h, "launch_pair: C must be 32, 64 or 128");
     }
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
@@ -669,6 +698,7 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     h->device = device;
     h->dims = *dims;
     { const char* fp = getenv("EV_FUSE_PAIRS"); if (fp && *fp == '0') h->fuse_pairs = false; }
+    { const char* fp = getenv("EV_FUSE128"); if (fp && *fp) h->fuse128 = atoi(fp); }
     if (dims->n_feats != 80 || dims->channels != 256 || dims->head_dim != 64 || dims->heads < 1 || dims->heads > 8) {
         delete h;
         return 4;
@@ -921,7 +951,7 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
                     e2.accum = (j > 0);
                     if (j == 2) { e2.div3 = 1; e2.act2_lrelu = 1; e2.act2_slope = (i == 3) ? 0.01f : 0.1f; }  // next consumer's leaky_relu
                 }
-                if (h->fuse_pairs && (C == 32 || C == 64)) {
+                if (h->fuse_pairs && (C == 32 || C == 64 || (C == 128 && h->fuse128 && w.c1[i * 3 + j][mm].ntaps <= h->fuse128))) {
                     // narrow stages: both convs of the pair in one launch, intermediate kept in LDS
                     if (launch_pair(h, w.c1[i * 3 + j][mm], w.c2[i * 3 + j][mm], x, y, C, v.g[l], e2)) return 1;
                 } else {

@@ -215,7 +215,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PF = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
@@ -314,9 +314,88 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     };
     const float* bbase = Xs + (wn * (TN * 32) + li + p.halo_lo) * EV_LDK + 4 * lh;
     const int2 tv_first = (nact > 0) ? tl[0] : make_int2(0, 0);
+    if constexpr (PF) {
+        // ---- software-pipelined X staging.  The X tile of chunk c+1 is loaded into registers while chunk c's MFMAs
+        // run and is written to LDS after them, so no wave ever waits for HBM inside the K loop — this is what a
+        // launch that fits the chip in ONE round of workgroups needs (every workgroup is in the same phase, nobody
+        // else covers a stall).  vmcnt retires in order, so a later weight-fragment wait would also wait for the X
+        // loads: the A pipeline is therefore three k-groups deep (four static register sets), which puts the first
+        // such wait ~3 k-groups of MFMAs behind the X loads.
+        f32x4 xv[XPASS];
+        auto x_load = [&](int ch) {
+            const int c = ch * EV_BK + sc4;
+            const bool cok = c < p.Cin;
+            const unsigned xcol = (unsigned)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1));
+#pragma unroll
+            for (int q = 0; q < XPASS; ++q) {
+                const int r = q * 32 + srow;
+                const int gr = n0 - p.halo_lo + r;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (cok && r < xrows && gr >= 0 && gr < p.nrows) v = ev_bload4(rX, ((unsigned)gr * p.ldx + xcol) * 4u, 0);
+                xv[q] = v;
+            }
+        };
+        auto x_store = [&]() {
+#pragma unroll
+            for (int q = 0; q < XPASS; ++q) {
+                const int r = q * 32 + srow;
+                f32x4 v = xv[q];
+                if (p.pro_lrelu) {
+                    v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                    v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                }
+                if (r < xrows) *(f32x4*)(Xs + r * EV_LDK + sc4) = v;
+            }
+        };
+        f32x4 A2[TM], A3[TM];
+        x_load(0);
+        if (nact > 0) {
+            const unsigned a0 = a_off(tv_first.x, 0);
+            ldAp(A0, a0); ldAp(A1, a0 + 1024u); ldAp(A2, a0 + 2048u);
+        }
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __syncthreads();            // previous chunk's MFMAs are done with Xs
+            x_store();
+            __syncthreads();
+            if (ch + 1 < nchunks) x_load(ch + 1);
+            int tap = tv_first.x;
+            const float* brow = bbase + tv_first.y * EV_LDK;
+            ldB(B0, brow, 0);
+            int2 tv_pre = tl[nact > 1 ? 1 : 0];
+            for (int ti = 0; ti < nact; ++ti) {
+                const bool last_tap = (ti + 1 == nact);
+                const int2 ntv = last_tap ? tv_first : tv_pre;
+                tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
+                const float* nbrow = bbase + ntv.y * EV_LDK;
+                const unsigned ap = a_off(tap, ch * 4);
+                const unsigned nap = a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4);
+                const bool have_next = !(last_tap && ch + 1 == nchunks);
+                ldAp(A3, ap + 3072u); ldB(B1, brow, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(A0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (have_next) ldAp(A0, nap);
+                ldB(B0, brow, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(A1, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (have_next) ldAp(A1, nap + 1024u);
+                ldB(B1, brow, 3);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(A2, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (have_next) ldAp(A2, nap + 2048u);
+                if (!last_tap) ldB(B0, nbrow, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(A3, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                tap = ntv.x; brow = nbrow;
+            }
+        }
+    } else {
     if (nact > 0) ldAp(A0, a_off(tv_first.x, 0));
     for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();  // previous chunk's MFMAs are done with Xs
+        if (!(p.dbg & 8)) __syncthreads();  // previous chunk's MFMAs are done with Xs (dbg 8: timing-only ablation without barriers)
         {
             // ---- stage the X tile of this k-chunk (with the optional prologue leaky-relu): all loads first
             const int c = ch * EV_BK + sc4;
@@ -342,7 +421,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 if (r < xrows) *(f32x4*)(Xs + r * EV_LDK + sc4) = v;
             }
         }
-        __syncthreads();
+        if (!(p.dbg & 8)) __syncthreads();
         int tap = tv_first.x;
         const float* brow = bbase + tv_first.y * EV_LDK;
         ldB(B0, brow, 0);
@@ -378,6 +457,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             tap = ntap; brow = nbrow;
         }
     }
+    }   // !PF
 
     if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
     conv_epilogue<TM, TN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
