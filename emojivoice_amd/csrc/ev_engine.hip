@@ -345,8 +345,8 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
     {   // start stagger (see conv_gemm_kernel): only worth it when the grid is several rounds deep
-        const int slots = cfg == 0 ? 3 : ((cfg == 1 || cfg == 5) ? 4 : (cfg == 6 ? 5 : 3));
-        const long wgs = cfg == 5 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 191) / 192) : cfg == 6 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64) : cfg == 0 ? (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) : (cfg == 1 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) : (long)((L.Cout + 31) / 32) * ((g.nrows + 255) / 256));
+        const int slots = cfg == 0 ? 3 : ((cfg == 1 || cfg == 5 || cfg == 7) ? 4 : ((cfg == 6 || cfg == 8) ? 5 : 3));
+        const long wgs = (cfg == 5 || cfg == 7) ? (long)((L.Cout + 63) / 64) * ((g.nrows + 191) / 192) : (cfg == 6 || cfg == 8) ? (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64) : cfg == 0 ? (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) : (cfg == 1 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) : (long)((L.Cout + 31) / 32) * ((g.nrows + 255) / 256));
         p.stagger_slots = (wgs >= 256L * slots * 3) ? slots : 0;
         if (e.stagger >= 0) p.stagger_slots = e.stagger;
         static const char* senv = getenv("EV_STAGGER");
@@ -361,6 +361,12 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     } else if (cfg == 5) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 192, 2, 2>(p, h->stream);
+    } else if (cfg == 7) {   // 64 x 192 with register-prefetched X staging
+        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_cfg<64, 192, 2, 2, true>(p, h->stream);
+    } else if (cfg == 8) {   // 64 x 64 with register-prefetched X staging
+        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_cfg<64, 64, 2, 2, true>(p, h->stream);
     } else if (cfg == 6) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 64, 2, 2>(p, h->stream);
