@@ -283,13 +283,24 @@ int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** o
 // ---------------------------------------------------------------------------
 static int g_dbg_wgs_per_cu = 0;   // tools/conv_bench.py: cap workgroups per CU by over-allocating LDS (0 = off)
 
+template <int BM, int BN, int WM, int WN, bool PF, bool FULL>
+void launch_cfg2(const ConvParams& p, hipStream_t st);
+
+// dispatch on the epilogue flavour: layers without a transcendental activation run the compact build whose whole
+// code (K loop + epilogue) stays I-cache resident
 template <int BM, int BN, int WM, int WN, bool PF = false>
 void launch_cfg(const ConvParams& p, hipStream_t st) {
+    if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_cfg2<BM, BN, WM, WN, PF, false>(p, st);
+    else launch_cfg2<BM, BN, WM, WN, PF, true>(p, st);
+}
+
+template <int BM, int BN, int WM, int WN, bool PF, bool FULL>
+void launch_cfg2(const ConvParams& p, hipStream_t st) {
     // LDS holds the X tile during the K loop and, afterwards, one transposed 32-frame slab per wave for the epilogue
     constexpr size_t xs = (size_t)(BN + EV_HALO) * EV_LDK, es = (size_t)4 * 32 * (BM / WM + 4);
     size_t smem = (xs > es ? xs : es) * sizeof(float);
-    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
 int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {

@@ -106,7 +106,7 @@ __device__ __forceinline__ int ev_xcd_remap(int id, int nwg) {
 // Fused conv epilogue for one wave's (TM*32 channels) x (TN*32 frames) accumulator tile whose first channel / frame are
 // mw0 / nw0.  Es = this wave's private LDS slab [32][TM*32 + 4].  Must be called by all waves of the workgroup
 // (it contains workgroup barriers).
-template <int TM, int TN>
+template <int TM, int TN, bool FULL_ACT = true>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane,
                                               int win_lo = -0x7fffffff, int win_hi = 0x7fffffff) {
     const int li = lane & 31, lh = lane >> 5;
@@ -187,7 +187,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 for (int e = 0; e < 4; ++e) {
                     const int c = (co + e < p.Cout) ? co + e : p.Cout - 1;
                     float x = v[e] + bs[e];
-                    if (p.act) x = ev_act(x, p.act, p.act_slope, p.act_a, p.act_b, c);
+                    if constexpr (FULL_ACT) { if (p.act) x = ev_act(x, p.act, p.act_slope, p.act_a, p.act_b, c); }
+                    else { if (p.act == ACT_LRELU) x = ev_lrelu(x, p.act_slope); }   // compact build: no transcendental code in the I-cache
                     if (p.mask1) x *= rm;
                     x *= p.scale;
                     if (p.R) x += rr[q][e];
@@ -215,7 +216,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PF = false>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PF = false, bool FULL_ACT = true>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }   // !PF
 
     if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
-    conv_epilogue<TM, TN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    conv_epilogue<TM, TN, FULL_ACT>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -641,7 +642,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp)
     });
 
     // ---------------- epilogue: + b2 + x (residual re-read, L2-hot), optional running resblock mean, window [n0, n0 + out_rows)
-    conv_epilogue<TM, TN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
+    conv_epilogue<TM, TN, false>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
 }
 
 // ---------------------------------------------------------------------------
@@ -686,20 +687,48 @@ __global__ __launch_bounds__(256) void groupnorm_mish_kernel(const GNParams p) {
     const size_t rowbase = (size_t)b * p.S + p.P;
     const int cbase = g * p.CG + c4;
     const float cnt = (float)p.T * (float)p.CG;
+    // The (T x 32-channel) slab of one (utterance, group) is read from HBM/L2 ONCE and kept in registers when it fits
+    // (T <= GN_REG_PASSES * rows-per-pass, i.e. 768 frames = 8.9 s at 32 channels per group); longer utterances fall
+    // back to three passes over the (L2-resident) slab.
+    constexpr int GN_REG_PASSES = 24;
+    const bool in_regs = p.T <= GN_REG_PASSES * rpp;
+    f32x4 keep[GN_REG_PASSES];
 
     float s = 0.f;
-    for (int t = r0; t < p.T; t += rpp) {
-        f32x4 v = *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase);
-        s += (v[0] + v[1]) + (v[2] + v[3]);
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < GN_REG_PASSES; ++q) {
+            const int t = r0 + q * rpp;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (t < p.T) v = *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase);
+            keep[q] = v;
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+    } else {
+        for (int t = r0; t < p.T; t += rpp) {
+            f32x4 v = *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase);
+            s += (v[0] + v[1]) + (v[2] + v[3]);
+        }
     }
     const float mean = block_sum_256(s, red) / cnt;
-    float q = 0.f;
-    for (int t = r0; t < p.T; t += rpp) {
-        f32x4 v = *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase);
-        float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    float q2 = 0.f;
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < GN_REG_PASSES; ++q) {
+            if (r0 + q * rpp < p.T) {
+                const f32x4 v = keep[q];
+                float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+                q2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+    } else {
+        for (int t = r0; t < p.T; t += rpp) {
+            f32x4 v = *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase);
+            float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+            q2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
     }
-    const float var = block_sum_256(q, red) / cnt;
+    const float var = block_sum_256(q2, red) / cnt;
     const float rstd = 1.0f / sqrtf(var + p.eps);
     float ga[4], be[4], te[4];
 #pragma unroll
@@ -707,9 +736,8 @@ __global__ __launch_bounds__(256) void groupnorm_mish_kernel(const GNParams p) {
         ga[e] = p.gamma[cbase + e]; be[e] = p.beta[cbase + e];
         te[e] = (p.mode == 1) ? p.temb[cbase + e] : 0.f;
     }
-    for (int t = r0; t < p.T; t += rpp) {
+    auto apply = [&](int t, f32x4 v) {
         const size_t n = rowbase + t;
-        f32x4 v = *(const f32x4*)(p.X + n * p.ldx + cbase);
         const float m = p.rowmask[n];
         f32x4 o;
 #pragma unroll
@@ -724,6 +752,15 @@ __global__ __launch_bounds__(256) void groupnorm_mish_kernel(const GNParams p) {
             o[0] += r[0]; o[1] += r[1]; o[2] += r[2]; o[3] += r[3];
         }
         *(f32x4*)(p.Y + n * p.ldy + cbase) = o;
+    };
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < GN_REG_PASSES; ++q) {
+            const int t = r0 + q * rpp;
+            if (t < p.T) apply(t, keep[q]);
+        }
+    } else {
+        for (int t = r0; t < p.T; t += rpp) apply(t, *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase));
     }
 }
 
