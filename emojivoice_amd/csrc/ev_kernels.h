@@ -78,6 +78,14 @@ __device__ __forceinline__ void ev_bstore1(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, (int)voff_bytes, 0, 0);
 }
 
+// Tap-list entries are wave-uniform, but hipcc fetches them with a vector load and then treats everything derived from
+// them (weight-fragment soffset, LDS row offset) as divergent: every buffer_load got a waterfall loop
+// (v_readfirstlane / v_cmp / s_and_saveexec ...) and the offsets were recomputed with v_mul.  readfirstlane makes the
+// uniformity provable, so the descriptor offsets live in SGPRs (guide T20).
+__device__ __forceinline__ int2 ev_uniform(int2 v) {
+    return make_int2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y));
+}
+
 __device__ __forceinline__ float ev_lrelu(float v, float s) { return v > 0.f ? v : v * s; }
 __device__ __forceinline__ float ev_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float ev_mish(float x) { return x * tanhf(ev_softplus(x)); }
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: keeps fragment offsets in SGPRs
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, lh = lane >> 5;
 
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 
     // active (non-zero) taps of this M tile: a host-built compact list read with scalar loads
     const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
-    const int nact = p.nact_tab ? p.nact_tab[mt] : p.ntaps;
+    const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
 
     // Start stagger.  All tiles of a launch cost the same, so the workgroups that share a CU (dispatched together at
     // t = 0) would otherwise stay in lockstep for the whole launch: every CU runs its MFMA phases at the same time and
@@ -314,7 +322,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s4], b[j][s4], acc[i][j], 0, 0, 0);
     };
     const float* bbase = Xs + (wn * (TN * 32) + li + p.halo_lo) * EV_LDK + 4 * lh;
-    const int2 tv_first = (nact > 0) ? tl[0] : make_int2(0, 0);
+    const int2 tv_first = (nact > 0) ? ev_uniform(tl[0]) : make_int2(0, 0);
     if constexpr (PF) {
         // ---- software-pipelined X staging.  The X tile of chunk c+1 is loaded into registers while chunk c's MFMAs
         // run and is written to LDS after them, so no wave ever waits for HBM inside the K loop — this is what a
@@ -362,10 +370,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             int tap = tv_first.x;
             const float* brow = bbase + tv_first.y * EV_LDK;
             ldB(B0, brow, 0);
-            int2 tv_pre = tl[nact > 1 ? 1 : 0];
+            int2 tv_pre = tl[nact > 1 ? 1 : 0];                 // raw (vector) load; made uniform at its use one tap later
             for (int ti = 0; ti < nact; ++ti) {
                 const bool last_tap = (ti + 1 == nact);
-                const int2 ntv = last_tap ? tv_first : tv_pre;
+                const int2 ntv = last_tap ? tv_first : ev_uniform(tv_pre);
                 tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
                 const float* nbrow = bbase + ntv.y * EV_LDK;
                 const unsigned ap = a_off(tap, ch * 4);
@@ -426,10 +434,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         int tap = tv_first.x;
         const float* brow = bbase + tv_first.y * EV_LDK;
         ldB(B0, brow, 0);
-        int2 tv_pre = tl[nact > 1 ? 1 : 0];            // tap list entries are fetched one tap ahead of their use
+        int2 tv_pre = tl[nact > 1 ? 1 : 0];                 // raw (vector) load; made uniform at its use one tap later            // tap list entries are fetched one tap ahead of their use
         for (int ti = 0; ti < nact; ++ti) {
             const bool last_tap = (ti + 1 == nact);
-            const int2 ntv = last_tap ? tv_first : tv_pre;
+            const int2 ntv = last_tap ? tv_first : ev_uniform(tv_pre);
             tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
             const int ntap = ntv.x;
             const float* nbrow = bbase + ntv.y * EV_LDK;
@@ -498,7 +506,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp)
     float* Xs = smem;                                   // phase 1: [XROWS][EV_LDK]
     float* Ys = smem;                                   // phase 2 (aliases Xs): [NCH][YROWS][EV_LDK]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int li = lane & 31, lh = lane >> 5;
     const int srow = tid >> 3, sc4 = (tid & 7) * 4;
@@ -541,17 +549,17 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp)
         for (int b = 0; b < TN; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
-        const int2 tv_first = tl[0];
+        const int2 tv_first = ev_uniform(tl[0]);
         ldAp(A0, a_off(tv_first.x, 0));
         for (int ch = 0; ch < NCH; ++ch) {
             const float* bbase = chunk_base(ch);        // LDS row 0 of this chunk for this lane (stages + barriers inside)
             int tap = tv_first.x;
             const float* brow = bbase + tv_first.y * EV_LDK;
             ldB(B0, brow, 0);
-            int2 tv_pre = tl[nact > 1 ? 1 : 0];
+            int2 tv_pre = tl[nact > 1 ? 1 : 0];                 // raw (vector) load; made uniform at its use one tap later
             for (int ti = 0; ti < nact; ++ti) {
                 const bool last_tap = (ti + 1 == nact);
-                const int2 ntv = last_tap ? tv_first : tv_pre;
+                const int2 ntv = last_tap ? tv_first : ev_uniform(tv_pre);
                 tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
                 const float* nbrow = bbase + ntv.y * EV_LDK;
                 const unsigned ap = a_off(tap, ch * 4);
