@@ -129,9 +129,12 @@ def main():
     spk = model._sd["spk_emb.weight"][spk_ids]
     z = z * 0.667
 
-    def step():
+    def step_local():
         dec = model.engine.cfm_decode(mu, lengths, spk, z, n_ode, model.mel_std, model.mel_mean)   # denormalised mel
-        wav = voc(dec)
+        return voc(dec)
+
+    def step():
+        wav = step_local()
         return D.all_gather_waveforms(wav) if world > 1 else wav
 
     log(f"[bench] rank {rank}/{world}: weights loaded, B={B} T={T}; warmup {args.warmup} ...")
@@ -162,7 +165,7 @@ def main():
         # recorded on the launch stream around every conv launch of one extra, untimed-for-`value` step
         for e in (model.engine, voc.engine):
             e.profile_enable(True)
-        step()
+        step_local()                      # rank-local: no collective outside the timed region
         torch.cuda.synchronize()
         ms_c, fl_c, n_c = model.engine.profile_read()
         ms_v, fl_v, n_v = voc.engine.profile_read()
