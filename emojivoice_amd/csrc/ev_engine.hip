@@ -462,7 +462,9 @@ int launch_gn(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const fl
     p.X = X; p.ldx = ldx; p.Y = Y; p.ldy = ldy; p.gamma = gamma; p.beta = beta; p.rowmask = rowmask; p.temb = temb; p.R = R; p.ldr = ldr;
     p.S = g.S; p.P = g.P; p.T = g.T; p.CG = C / 8; p.mode = mode; p.eps = 1e-5f;
     if (p.CG != 32) return fail(h, "groupnorm kernel expects 32 channels per group, got %d", p.CG);
-    hipLaunchKernelGGL(groupnorm_mish_kernel, dim3(g.nrows / g.S, 8), dim3(256), 0, h->stream, p);
+    // small batches: 1024 threads per (utterance, group) shorten the per-workgroup latency chain (8 workgroups at B = 1)
+    if (g.nrows / g.S < 32) hipLaunchKernelGGL(groupnorm_mish_kernel<1024>, dim3(g.nrows / g.S, 8), dim3(1024), 0, h->stream, p);
+    else hipLaunchKernelGGL(groupnorm_mish_kernel<256>, dim3(g.nrows / g.S, 8), dim3(256), 0, h->stream, p);
     HIPCHK(h, hipGetLastError());
     return 0;
 }

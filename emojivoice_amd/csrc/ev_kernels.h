@@ -662,12 +662,16 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* red /*[4]*/) {
+template <int NTHR>
+__device__ __forceinline__ float block_sum(float v, float* red /*[NTHR/64]*/) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTHR / 64; ++i) t += red[i];
+    return t;
 }
 
 // ---------------------------------------------------------------------------
@@ -685,20 +689,21 @@ struct GNParams {
     int S, P, T, CG; int mode; float eps;
 };
 
-__global__ __launch_bounds__(256) void groupnorm_mish_kernel(const GNParams p) {
-    __shared__ float red[4];
+template <int NTHR>
+__global__ __launch_bounds__(NTHR) void groupnorm_mish_kernel(const GNParams p) {
+    __shared__ float red[NTHR / 64];
     const int b = blockIdx.x, g = blockIdx.y;
     const int tid = threadIdx.x;
     const int c4n = p.CG / 4;            // float4 columns per row
-    const int rpp = 256 / c4n;           // rows per pass
+    const int rpp = NTHR / c4n;          // rows per pass
     const int r0 = tid / c4n, c4 = (tid % c4n) * 4;
     const size_t rowbase = (size_t)b * p.S + p.P;
     const int cbase = g * p.CG + c4;
     const float cnt = (float)p.T * (float)p.CG;
     // The (T x 32-channel) slab of one (utterance, group) is read from HBM/L2 ONCE and kept in registers when it fits
-    // (T <= GN_REG_PASSES * rows-per-pass, i.e. 768 frames = 8.9 s at 32 channels per group); longer utterances fall
+    // (T <= GN_REG_PASSES * rows-per-pass: 768 frames with 256 threads, 1024 with the 1024-thread build used for small batches); longer utterances fall
     // back to three passes over the (L2-resident) slab.
-    constexpr int GN_REG_PASSES = 24;
+    constexpr int GN_REG_PASSES = NTHR == 256 ? 24 : 8;
     const bool in_regs = p.T <= GN_REG_PASSES * rpp;
     f32x4 keep[GN_REG_PASSES];
 
@@ -718,7 +723,7 @@ __global__ __launch_bounds__(256) void groupnorm_mish_kernel(const GNParams p) {
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }
     }
-    const float mean = block_sum_256(s, red) / cnt;
+    const float mean = block_sum<NTHR>(s, red) / cnt;
     float q2 = 0.f;
     if (in_regs) {
 #pragma unroll
@@ -736,7 +741,7 @@ __global__ __launch_bounds__(256) void groupnorm_mish_kernel(const GNParams p) {
             q2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
         }
     }
-    const float var = block_sum_256(q2, red) / cnt;
+    const float var = block_sum<NTHR>(q2, red) / cnt;
     const float rstd = 1.0f / sqrtf(var + p.eps);
     float ga[4], be[4], te[4];
 #pragma unroll
