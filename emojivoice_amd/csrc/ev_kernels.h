@@ -854,28 +854,35 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
     float mrun = -1e30f, lrun = 0.f;
 
     const int nkt = (p.T + 31) / 32;
+    // K/V tiles are staged through registers one tile ahead: the global loads of tile kt+1 fly while tile kt is being
+    // multiplied, so the per-tile critical path is LDS + MFMA only (matters most at small batch, where a workgroup's
+    // 9-17 key tiles are a serial chain).
+    const int sr = tid >> 3;             // key row within the tile, 0..31
+    const int sc = (tid & 7) * 8;        // first of 8 dims, 0..56
+    f32x4 k0, k1, v0, v1;
+    float mk;
+    auto kv_load = [&](int kt) {
+        const int tk = kt * 32 + sr;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        k0 = z; k1 = z; v0 = z; v1 = z;
+        if (tk < p.T) {
+            const float* kr = Kp + (rowbase + tk) * p.ld + sc;
+            const float* vr = Vp + (rowbase + tk) * p.ld + sc;
+            k0 = *(const f32x4*)kr; k1 = *(const f32x4*)(kr + 4);
+            v0 = *(const f32x4*)vr; v1 = *(const f32x4*)(vr + 4);
+        }
+        const int tm = kt * 32 + (tid & 31);
+        mk = (tm < p.T) ? p.rowmask[rowbase + tm] : -1e30f;
+    };
+    kv_load(0);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        // stage 32 keys x 64 dims of K and V (rows past T read zero pad / neighbour rows: finite, masked below)
-        {
-            const int r = tid >> 3;          // 0..31
-            const int c = (tid & 7) * 8;     // 0..56
-            const int tk = kt * 32 + r;
-            f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
-            if (tk < p.T) {
-                const float* kr = Kp + (rowbase + tk) * p.ld + c;
-                const float* vr = Vp + (rowbase + tk) * p.ld + c;
-                k0 = *(const f32x4*)kr; k1 = *(const f32x4*)(kr + 4);
-                v0 = *(const f32x4*)vr; v1 = *(const f32x4*)(vr + 4);
-            }
-            *(f32x4*)(Ks + r * ATT_LDK + c) = k0; *(f32x4*)(Ks + r * ATT_LDK + c + 4) = k1;
-            *(f32x4*)(Vs + r * ATT_LDK + c) = v0; *(f32x4*)(Vs + r * ATT_LDK + c + 4) = v1;
-            if (tid < 32) {
-                const int tm = kt * 32 + tid;
-                Ms[tid] = (tm < p.T) ? p.rowmask[rowbase + tm] : -1e30f;
-            }
-        }
+        // publish the prefetched 32 keys x 64 dims of K and V (rows past T are zero, masked below)
+        *(f32x4*)(Ks + sr * ATT_LDK + sc) = k0; *(f32x4*)(Ks + sr * ATT_LDK + sc + 4) = k1;
+        *(f32x4*)(Vs + sr * ATT_LDK + sc) = v0; *(f32x4*)(Vs + sr * ATT_LDK + sc + 4) = v1;
+        if (tid < 32) Ms[tid] = mk;
         __syncthreads();
+        if (kt + 1 < nkt) kv_load(kt + 1);
         // S^T[key][q] = sum_d K[key][d] * Q[q][d]
         f32x16 s;
 #pragma unroll
