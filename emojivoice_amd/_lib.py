@@ -193,7 +193,13 @@ class Engine:
         B, F, T = mel.shape
         assert F == 80
         wav = torch.empty((B, 1, T * 256), dtype=torch.float32, device=mel.device)
-        self._check(self.lib.ev_hifigan(self.h, mel.data_ptr(), B, T, wav.data_ptr(), _stream_ptr()), "ev_hifigan")
+        # the kernels address tensors with 32-bit byte offsets (< 4 GiB each): the widest vocoder tensor holds
+        # 256 * (T + 8) frames x 128 B per utterance (levels 2-4), so very large batches are processed in row chunks
+        per_utt = 256 * (T + 8) * 128
+        bmax = max(1, int((2**32 - 2**20) // per_utt))
+        for b0 in range(0, B, bmax):
+            b1 = min(B, b0 + bmax)
+            self._check(self.lib.ev_hifigan(self.h, mel[b0:b1].data_ptr(), b1 - b0, T, wav[b0:b1].data_ptr(), _stream_ptr()), "ev_hifigan")
         return wav
 
     def workspace_bytes(self, B: int, Tp: int, Tv: int) -> int:

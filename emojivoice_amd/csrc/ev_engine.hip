@@ -318,6 +318,12 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope; p.mask2 = e.mask2; p.rowmask = e.rowmask;
     p.Y2 = e.Y2; p.ldy2 = e.ldy2; p.dbg = e.dbg;
     if ((ldx & 3) || (L.Cin & 3)) return fail(h, "conv input must be float4-aligned (ldx %d Cin %d)", ldx, L.Cin);
+    {   // buffer (SRSRC) addressing uses 32-bit byte offsets: every tensor of a launch must stay below 4 GiB
+        const double lim = 4294967296.0;
+        const double ymax = (double)g.nrows * ldy * 4.0, xmax = (double)g.nrows * ldx * 4.0;
+        if (xmax >= lim || ymax >= lim || (e.R && (double)g.nrows * e.ldr * 4.0 >= lim) || (e.Y2 && (double)g.nrows * e.ldy2 * 4.0 >= lim))
+            return fail(h, "tensor of %.1f GiB exceeds the 4 GiB buffer-addressing limit: split the batch", (xmax > ymax ? xmax : ymax) / 1073741824.0);
+    }
 
     // Tile choice.  cfg: 0 = 128x128, 1 = 64x128, 2 = 32x256, 5 = 64x192, 6 = 64x64 (channels x frames per workgroup).
     // A launch that fits the chip in about one round of workgroups is decided by its makespan: e.g. 1040 tiles on
@@ -415,6 +421,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     p.scale = 1.f; p.R = X; p.ldr = C; p.accum = e.accum; p.div3 = e.div3; p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope;
     pp.W1 = L1.W; pp.b1 = L1.bias; pp.taplist1 = L1.taplist[0]; pp.ntaps1 = L1.ntaps;
     pp.h1 = L1.halo_lo; pp.h2 = L2.halo_lo; pp.mid_slope = 0.1f;
+    if ((double)g.nrows * C * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
     if (L1.sparse_taps || L2.sparse_taps || L1.Kpad != C || L2.Kpad != C || L1.Kpad != L2.Kpad || L1.Mpad != L2.Mpad || L1.halo_lo != L1.halo_hi ||
         L2.halo_lo != L2.halo_hi || 2 * pp.h2 > 16 || !L1.bias || !L2.bias)
         return fail(h, "launch_pair: unsupported layer pair");

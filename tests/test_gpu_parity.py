@@ -230,3 +230,13 @@ def test_single_speaker_model_vs_oracle():
     if not np.array_equal(got["mel_lengths"].cpu().numpy(), ref["mel_lengths"].numpy()):
         pytest.skip("GPU/CPU text-encoder rounding flipped a ceil() in the durations for this seed")
     assert _linf(got["mel"], ref["mel"]) <= MEL_GATE
+
+
+def test_vocoder_batch_chunking_matches(vocoder):
+    """Batches beyond the 4 GiB-per-tensor buffer-addressing limit are split by rows: the result must not depend on
+    where the split falls (the vocoder has no cross-utterance coupling)."""
+    g = torch.Generator().manual_seed(21)
+    mel = (torch.randn(5, 80, 24, generator=g) * 2 - 5).cuda()
+    full = vocoder(mel)
+    parts = torch.cat([vocoder(mel[:2]), vocoder(mel[2:])], dim=0)
+    assert _linf(full, parts.cpu()) <= 1e-6
