@@ -47,7 +47,7 @@ struct Epi {
     int act2_lrelu = 0; float act2_slope = 0.f; int mask2 = 0; const float* rowmask = nullptr; int mmul = 1;
     float* Y2 = nullptr; int ldy2 = 0;
     float pro_slope = -1.f;                 // >= 0: prologue leaky-relu on the input
-    int dbg = 0; int force_cfg = -1; int stagger = -1;
+    int dbg = 0; int force_cfg = -1; int stagger = -1; unsigned long long* stamps = nullptr;
     int isplit_log2 = 31, isstride = 0;     // input column split (pair view of a strided slice)
     int osplit_log2 = 31, osstride = 0;     // output column split
 };
@@ -281,6 +281,7 @@ int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** o
 // ---------------------------------------------------------------------------
 // launching
 // ---------------------------------------------------------------------------
+static int g_xrows_halo = EV_HALO;   // halo rows of the layer being launched (LDS is sized for BN + halo, not BN + EV_HALO)
 static int g_dbg_wgs_per_cu = 0;   // tools/conv_bench.py: cap workgroups per CU by over-allocating LDS (0 = off)
 
 template <int BM, int BN, int WM, int WN, bool PF, bool FULL>
@@ -297,7 +298,8 @@ void launch_cfg(const ConvParams& p, hipStream_t st) {
 template <int BM, int BN, int WM, int WN, bool PF, bool FULL>
 void launch_cfg2(const ConvParams& p, hipStream_t st) {
     // LDS holds the X tile during the K loop and, afterwards, one transposed 32-frame slab per wave for the epilogue
-    constexpr size_t xs = (size_t)(BN + EV_HALO) * EV_LDK, es = (size_t)4 * 32 * (BM / WM + 4);
+    const size_t xs = (size_t)(BN + ((g_xrows_halo + 7) & ~7)) * EV_LDK;
+    constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4);
     size_t smem = (xs > es ? xs : es) * sizeof(float);
     if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
@@ -316,7 +318,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     p.act = e.act; p.act_slope = e.act_slope; p.act_a = e.act_a; p.act_b = e.act_b;
     p.mask1 = e.mask1; p.scale = e.scale; p.R = e.R; p.ldr = e.ldr; p.accum = e.accum; p.div3 = e.div3;
     p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope; p.mask2 = e.mask2; p.rowmask = e.rowmask;
-    p.Y2 = e.Y2; p.ldy2 = e.ldy2; p.dbg = e.dbg;
+    p.Y2 = e.Y2; p.ldy2 = e.ldy2; p.dbg = e.dbg; p.stamps = e.stamps;
     if ((ldx & 3) || (L.Cin & 3)) return fail(h, "conv input must be float4-aligned (ldx %d Cin %d)", ldx, L.Cin);
     {   // buffer (SRSRC) addressing uses 32-bit byte offsets: every tensor of a launch must stay below 4 GiB
         const double lim = 4294967296.0;
@@ -356,6 +358,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     }
     g_dbg_wgs_per_cu = 0;
     if (e.force_cfg >= 0) { cfg = e.force_cfg % 100; g_dbg_wgs_per_cu = e.force_cfg / 100; }
+    g_xrows_halo = L.halo_lo + L.halo_hi;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         if (h->ev_used + 2 > h->ev_pool.size()) {
@@ -1031,7 +1034,8 @@ int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* 
 // (prologue lrelu, bias, residual) at a given geometry with HIP events; dbg = ablation bits, cfg = forced tile config.
 int ev_dbg_conv_bench(ev_handle* h, int Cin, int Cout, int K, int dil, int B, int T, int P, int iters, int dbg, int cfg, float* ms_out) {
     const int stagger = (dbg & 64) ? 0 : -1;   // bit 64: disable the start stagger
-    dbg &= ~64;
+    const bool planar = (dbg & 32) != 0;      // bit 32: channel-chunk-planar activations
+    dbg &= ~(64 | 32);
     if (!h) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     h->stream = nullptr;
@@ -1055,17 +1059,40 @@ int ev_dbg_conv_bench(ev_handle* h, int Cin, int Cout, int K, int dil, int B, in
     for (size_t o = 0; o < nx; o += xh.size()) HIPCHK(h, hipMemcpy(X + o, xh.data(), std::min(xh.size(), nx - o) * 4, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(Y, 0, ny * 4));
     Epi e; e.pro_slope = 0.1f; e.dbg = dbg; e.force_cfg = cfg; e.stagger = stagger;
+    unsigned long long* d_st = nullptr;
+    const size_t max_wgs = 1 << 16;
+    if (dbg & 16) { HIPCHK(h, hipMalloc((void**)&d_st, max_wgs * 4 * 8)); HIPCHK(h, hipMemset(d_st, 0, max_wgs * 4 * 8)); e.stamps = d_st; }
     if (Cin == Cout) { e.R = X; e.ldr = Cin; }
+    int ldx_b = Cin, ldy_b = Cout;
+    if (planar) {   // channel-chunk-planar layout: [C/32 planes][rows][32]
+        e.isplit_log2 = 5; e.isstride = g.nrows * 32; e.osplit_log2 = 5; e.osstride = g.nrows * 32; ldx_b = 32; ldy_b = 32;
+        if (e.R) e.ldr = 32;
+    }
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
-    int rc = launch_conv(h, L, X, Cin, Y, Cout, g, e);   // warm-up
+    int rc = launch_conv(h, L, X, ldx_b, Y, ldy_b, g, e);   // warm-up
     HIPCHK(h, hipEventRecord(e0, nullptr));
-    for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(h, L, X, Cin, Y, Cout, g, e);
+    for (int i = 0; i < iters && !rc; ++i) rc = launch_conv(h, L, X, ldx_b, Y, ldy_b, g, e);
     HIPCHK(h, hipEventRecord(e1, nullptr));
     HIPCHK(h, hipEventSynchronize(e1));
     float ms = 0;
     HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
     if (ms_out) *ms_out = ms / (float)iters;
+    if (d_st) {   // timeline of the LAST launch: percentiles of the four per-workgroup stamps relative to the earliest start
+        std::vector<unsigned long long> st(max_wgs * 4);
+        HIPCHK(h, hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> v[4];
+        unsigned long long t0 = ~0ull;
+        for (size_t i = 0; i < max_wgs; ++i) if (st[4 * i] && st[4 * i] < t0) t0 = st[4 * i];
+        for (size_t i = 0; i < max_wgs; ++i) if (st[4 * i]) for (int k = 0; k < 4; ++k) v[k].push_back((double)(st[4 * i + k] - t0) / 100.0);  // 100 MHz -> us
+        const char* nm[4] = {"start", "stage0", "kloop", "end"};
+        for (int k = 0; k < 4; ++k) {
+            std::sort(v[k].begin(), v[k].end());
+            const size_t n = v[k].size();
+            if (n) fprintf(stderr, "  stamp %-6s n=%zu  min %.1f  p10 %.1f  p50 %.1f  p90 %.1f  max %.1f us\n", nm[k], n, v[k][0], v[k][n / 10], v[k][n / 2], v[k][n * 9 / 10], v[k][n - 1]);
+        }
+        hipFree(d_st);
+    }
     hipEventDestroy(e0); hipEventDestroy(e1);
     hipFree(X); hipFree(Y);
     while (h->owned.size() > owned0) { hipFree(h->owned.back()); h->owned.pop_back(); }

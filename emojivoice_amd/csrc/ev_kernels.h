@@ -54,6 +54,7 @@ struct ConvParams {
     const float* rowmask;
     float* Y2; int ldy2;                    // optional second output = v * rowmask
     int stagger_slots;                      // workgroups co-resident per CU (0 = no start stagger), see conv_gemm_kernel
+    unsigned long long* stamps;             // dbg bit 16: per-workgroup {start, first stage done, K loop done, end} s_memtime stamps
     int dbg;                                // ablation bits for tools/conv_bench.py: 1 skip X loads, 2 skip A loads, 4 skip epilogue
 };
 
@@ -224,8 +225,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
 }
 
+#ifndef EV_CONV_MIN_WAVES
+#define EV_CONV_MIN_WAVES 1
+#endif
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool PF = false, bool FULL_ACT = true>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
+__global__ __launch_bounds__(256, (BM == 64 && !PF && !FULL_ACT) ? EV_CONV_MIN_WAVES : 1) void conv_gemm_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     // active (non-zero) taps of this M tile: a host-built compact list read with scalar loads
     const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
     const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
+    if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
 
     // Start stagger.  All tiles of a launch cost the same, so the workgroups that share a CU (dispatched together at
     // t = 0) would otherwise stay in lockstep for the whole launch: every CU runs its MFMA phases at the same time and
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             }
         }
         if (!(p.dbg & 8)) __syncthreads();
+        if ((p.dbg & 16) && ch == 0 && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         int tap = tv_first.x;
         const float* brow = bbase + tv_first.y * EV_LDK;
         ldB(B0, brow, 0);
@@ -468,8 +474,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
     }   // !PF
 
+    if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
     conv_epilogue<TM, TN, FULL_ACT>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---------------------------------------------------------------------------
