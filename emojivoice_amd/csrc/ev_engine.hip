@@ -90,6 +90,8 @@ struct ev_handle {
     int fuse128 = 3;            // fuse C=128 pairs up to this kernel size (EV_FUSE128=0/3/7/11)
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     double prof_flops = 0; int64_t prof_launches = 0;
+    struct ProfRec { int kind, Cin, Cout, ntaps, nrows, cfg, lean; double flops; };
+    std::vector<ProfRec> prof_recs;   // one per timed launch (EV_PROFILE_DUMP=<file> writes the per-shape table)
     hipStream_t stream = nullptr;
 };
 
@@ -284,25 +286,37 @@ int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** o
 static int g_xrows_halo = EV_HALO;   // halo rows of the layer being launched (LDS is sized for BN + halo, not BN + EV_HALO)
 static int g_dbg_wgs_per_cu = 0;   // tools/conv_bench.py: cap workgroups per CU by over-allocating LDS (0 = off)
 
-template <int BM, int BN, int WM, int WN, bool PF, bool FULL>
+template <int BM, int BN, int WM, int WN, bool PF, bool FULL, int LEAN>
 void launch_cfg2(const ConvParams& p, hipStream_t st);
 
-// dispatch on the epilogue flavour: layers without a transcendental activation run the compact build whose whole
-// code (K loop + epilogue) stays I-cache resident
+// Dispatch on the epilogue flavour:
+//   lean    : y = act(acc + bias) [+ R], act in {none, lrelu, SnakeBeta}, plain row-major Y/R, Cout % 4 == 0
+//             (instruction-lean, bias preloaded into acc)
+//   compact : any flag combination without a transcendental activation (code stays I-cache resident)
+//   full    : tanh / SiLU / Mish / SnakeBeta
+inline bool lean_ok(const ConvParams& p) {
+    return (p.act == ACT_NONE || p.act == ACT_LRELU || (p.act == ACT_SNAKE && (((size_t)p.act_a | (size_t)p.act_b) & 15) == 0)) && !p.mask1 && !p.mask2 && p.scale == 1.f && !p.accum && !p.div3 && !p.act2_lrelu &&
+           !p.Y2 && !p.rowmask && p.osplit_log2 >= 31 && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (!p.R || (p.ldr & 3) == 0) &&
+           (!p.bias || ((size_t)p.bias & 15) == 0) && !(p.dbg & 4);
+}
 template <int BM, int BN, int WM, int WN, bool PF = false>
 void launch_cfg(const ConvParams& p, hipStream_t st) {
-    if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_cfg2<BM, BN, WM, WN, PF, false>(p, st);
-    else launch_cfg2<BM, BN, WM, WN, PF, true>(p, st);
+    static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
+    if (!no_lean && lean_ok(p)) {
+        if (p.act == ACT_SNAKE) launch_cfg2<BM, BN, WM, WN, PF, false, 2>(p, st);
+        else launch_cfg2<BM, BN, WM, WN, PF, false, 1>(p, st);
+    } else if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_cfg2<BM, BN, WM, WN, PF, false, 0>(p, st);
+    else launch_cfg2<BM, BN, WM, WN, PF, true, 0>(p, st);
 }
 
-template <int BM, int BN, int WM, int WN, bool PF, bool FULL>
+template <int BM, int BN, int WM, int WN, bool PF, bool FULL, int LEAN>
 void launch_cfg2(const ConvParams& p, hipStream_t st) {
     // LDS holds the X tile during the K loop and, afterwards, one transposed 32-frame slab per wave for the epilogue
     const size_t xs = (size_t)(BN + ((g_xrows_halo + 7) & ~7)) * EV_LDK;
     constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4);
     size_t smem = (xs > es ? xs : es) * sizeof(float);
-    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF, FULL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
 int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {
@@ -406,6 +420,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         const double valid_rows = (double)(g.nrows / g.S) * g.T;
         h->prof_flops += 2.0 * L.macs_per_row * valid_rows;
         h->prof_launches += 1;
+        h->prof_recs.push_back({0, L.Cin, L.Cout, L.ntaps, g.nrows, cfg, (int)lean_ok(p), 2.0 * L.macs_per_row * valid_rows});
     }
     return 0;
 }
@@ -462,6 +477,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         const double valid_rows = (double)(g.nrows / g.S) * g.T;
         h->prof_flops += 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows;
         h->prof_launches += 1;
+        h->prof_recs.push_back({1, C, C, L1.ntaps, g.nrows, 100 + L2.ntaps, 0, 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows});
     }
     return 0;
 }
@@ -1010,7 +1026,7 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
 int ev_profile_enable(ev_handle* h, int on) {
     if (!h) return 1;
     h->prof = on != 0;
-    h->ev_used = 0; h->prof_flops = 0; h->prof_launches = 0;
+    h->ev_used = 0; h->prof_flops = 0; h->prof_launches = 0; h->prof_recs.clear();
     return 0;
 }
 
@@ -1023,10 +1039,33 @@ int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* 
         HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[i], h->ev_pool[i + 1]));
         ms += t;
     }
+    if (const char* dump = getenv("EV_PROFILE_DUMP")) {
+        if (*dump && h->prof_recs.size() * 2 == h->ev_used) {
+            struct Agg { ev_handle::ProfRec r; double ms = 0, fl = 0; int n = 0; };
+            std::vector<Agg> aggs;
+            for (size_t i = 0; i < h->prof_recs.size(); ++i) {
+                const auto& r = h->prof_recs[i];
+                float t = 0;
+                hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]);
+                Agg* a = nullptr;
+                for (auto& x : aggs)
+                    if (x.r.kind == r.kind && x.r.Cin == r.Cin && x.r.Cout == r.Cout && x.r.ntaps == r.ntaps && x.r.nrows == r.nrows && x.r.cfg == r.cfg && x.r.lean == r.lean) a = &x;
+                if (!a) { aggs.push_back(Agg{r}); a = &aggs.back(); }
+                a->ms += t; a->fl += r.flops; a->n += 1;
+            }
+            if (FILE* f = fopen(dump, "a")) {
+                fprintf(f, "# kind Cin Cout ntaps nrows cfg lean launches total_ms TFLOP/s\n");
+                for (auto& a : aggs)
+                    fprintf(f, "%s %4d %4d %3d %9d %3d %d %5d %9.3f %7.1f\n", a.r.kind ? "pair" : "conv", a.r.Cin, a.r.Cout, a.r.ntaps, a.r.nrows, a.r.cfg, a.r.lean,
+                            a.n, a.ms, a.fl / (a.ms * 1e9));
+                fclose(f);
+            }
+        }
+    }
     if (conv_ms) *conv_ms = ms;
     if (conv_flops) *conv_flops = h->prof_flops;
     if (conv_launches) *conv_launches = h->prof_launches;
-    if (reset) { h->ev_used = 0; h->prof_flops = 0; h->prof_launches = 0; }
+    if (reset) { h->ev_used = 0; h->prof_flops = 0; h->prof_launches = 0; h->prof_recs.clear(); }
     return 0;
 }
 
@@ -1035,7 +1074,8 @@ int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* 
 int ev_dbg_conv_bench(ev_handle* h, int Cin, int Cout, int K, int dil, int B, int T, int P, int iters, int dbg, int cfg, float* ms_out) {
     const int stagger = (dbg & 64) ? 0 : -1;   // bit 64: disable the start stagger
     const bool planar = (dbg & 32) != 0;      // bit 32: channel-chunk-planar activations
-    dbg &= ~(64 | 32);
+    const bool no_res = (dbg & 128) != 0;     // bit 128: no residual input
+    dbg &= ~(64 | 32 | 128);
     if (!h) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     h->stream = nullptr;
@@ -1062,7 +1102,7 @@ int ev_dbg_conv_bench(ev_handle* h, int Cin, int Cout, int K, int dil, int B, in
     unsigned long long* d_st = nullptr;
     const size_t max_wgs = 1 << 16;
     if (dbg & 16) { HIPCHK(h, hipMalloc((void**)&d_st, max_wgs * 4 * 8)); HIPCHK(h, hipMemset(d_st, 0, max_wgs * 4 * 8)); e.stamps = d_st; }
-    if (Cin == Cout) { e.R = X; e.ldr = Cin; }
+    if (Cin == Cout && !no_res) { e.R = X; e.ldr = Cin; }
     int ldx_b = Cin, ldy_b = Cout;
     if (planar) {   // channel-chunk-planar layout: [C/32 planes][rows][32]
         e.isplit_log2 = 5; e.isstride = g.nrows * 32; e.osplit_log2 = 5; e.osstride = g.nrows * 32; ldx_b = 32; ldy_b = 32;

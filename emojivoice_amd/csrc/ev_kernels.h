@@ -92,13 +92,29 @@ __device__ __forceinline__ float ev_softplus(float x) { return x > 20.f ? x : lo
 __device__ __forceinline__ float ev_mish(float x) { return x * tanhf(ev_softplus(x)); }
 __device__ __forceinline__ float ev_silu(float x) { return x / (1.f + expf(-x)); }
 
+// sin^2(u) in ~17 VALU instructions (the SnakeBeta feed-forward epilogue evaluates 34 M of these per launch; ocml's
+// sinf with its Payne-Hanek tail made that epilogue cost more than the GEMM in front of it).  Cody-Waite reduction by
+// pi/2 with three fma steps, the cephes single-precision sine polynomial on |r| <= pi/4, and sin^2 = 1 - sin^2 on odd
+// quadrants.  Absolute error <= 2e-7 for |u| <= 1e4 (hidden activations are O(10)); degrades gracefully beyond that.
+__device__ __forceinline__ float ev_sin2(float u) {
+    const float k = rintf(u * 0.63661977236758134f);
+    float r = fmaf(k, -1.57079637050628662109375f, u);
+    r = fmaf(k, 4.371138828673793e-8f, r);
+    r = fmaf(k, 1.7763568394002505e-15f, r);
+    const float z = r * r;
+    const float q = fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+    const float sn = fmaf(q * z, r, r);
+    const float s2 = sn * sn;
+    return ((int)k & 1) ? 1.f - s2 : s2;
+}
+
 __device__ __forceinline__ float ev_act(float v, int act, float slope, const float* a, const float* b, int co) {
     switch (act) {
         case ACT_LRELU: return ev_lrelu(v, slope);
         case ACT_TANH: return tanhf(v);
         case ACT_SILU: return ev_silu(v);
         case ACT_MISH: return ev_mish(v);
-        case ACT_SNAKE: { float s = sinf(v * a[co]); return v + b[co] * (s * s); }
+        case ACT_SNAKE: return fmaf(b[co], ev_sin2(v * a[co]), v);
         default: return v;
     }
 }
@@ -111,6 +127,12 @@ __device__ __forceinline__ int ev_xcd_remap(int id, int nwg) {
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + within;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence: hipcc emits s_waitcnt vmcnt(0) in front
+// of it, i.e. it also waits for every global STORE this wave still has in flight — in the conv epilogue that made each
+// slab's barrier wait for the previous slab's stores to be acknowledged by memory (30-60 us per workgroup, measured
+// with the per-workgroup stamps in profiles/r01_conv_workgroup_timelines.log).
+__device__ __forceinline__ void ev_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Fused conv epilogue for one wave's (TM*32 channels) x (TN*32 frames) accumulator tile whose first channel / frame are
 // mw0 / nw0.  Es = this wave's private LDS slab [32][TM*32 + 4].  Must be called by all waves of the workgroup
@@ -174,7 +196,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 }
             }
             if (pb == 0) {
-                __syncthreads();             // LDS free (K loop done / previous slab consumed)
+                ev_lds_barrier();            // LDS free (K loop done / previous slab consumed)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -182,7 +204,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                         f32x4 q4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                         *(f32x4*)(Es + li * ELD + i * 32 + 8 * g + 4 * lh) = q4;
                     }
-                __syncthreads();
+                ev_lds_barrier();
             }
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
@@ -228,8 +250,91 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 #ifndef EV_CONV_MIN_WAVES
 #define EV_CONV_MIN_WAVES 1
 #endif
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PF = false, bool FULL_ACT = true>
-__global__ __launch_bounds__(256, (BM == 64 && !PF && !FULL_ACT) ? EV_CONV_MIN_WAVES : 1) void conv_gemm_kernel(const ConvParams p) {
+// ---------------------------------------------------------------------------
+// Instruction-lean epilogue.  Per-workgroup stamps (profiles/r01_conv_workgroup_timelines.log) show the generic epilogue
+// taking 30-60 us of a 80-210 us workgroup lifetime, and the longer the more the co-resident waves are MFMA-busy: every
+// vector instruction of a memory-phase wave waits behind the 64-cycle fp32 MFMAs of its SIMD, so epilogue time is
+// (number of vector instructions) x (MFMA issue slot).  This version serves the layers whose epilogue is
+//     y = act(acc + bias) [+ R]          act in {none, leaky-relu},  Cout % 4 == 0, plain row-major Y / R
+// with ~10x fewer vector instructions: the bias is preloaded into the accumulators by the caller, row bookkeeping is
+// incremental (one modulo per lane), the per-wave LDS transposition needs no workgroup barrier after the first one,
+// and the residual rows of slab j+1 are requested before slab j's stores (vmcnt retires in order).
+// ---------------------------------------------------------------------------
+template <int TM, int TN, bool SNAKE = false>
+__device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane,
+                                                   int win_lo = -0x7fffffff, int win_hi = 0x7fffffff) {
+    constexpr int EC = TM * 32, ELD = EC + 4, C4 = EC / 4, RPP = 64 / C4, NP = 32 / RPP;
+    const int li = lane & 31, lh = lane >> 5;
+    const int er = lane / C4, ec = (lane % C4) * 4;
+    const int co = mw0 + ec;
+    const bool co_ok = co < p.Cout;
+    const __amdgpu_buffer_rsrc_t rY = ev_rsrc(p.Y), rR = ev_rsrc(p.R);
+    const bool has_r = p.R != nullptr;
+    const bool do_act = p.act == ACT_LRELU;
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
+    if constexpr (SNAKE) {
+        if (co_ok) { sa = *(const f32x4*)(p.act_a + co); sb = *(const f32x4*)(p.act_b + co); }
+    }
+    // row bookkeeping for this lane: rows n0l, n0l + RPP, ... ; t = position inside the utterance
+    const int n0l = nw0 + er;
+    int t = n0l % p.S;
+    if (t < 0) t += p.S;                              // (only the fused pair kernel starts before row 0)
+    t -= p.P;
+    unsigned yoff = ((unsigned)n0l * p.ldy + co) * 4u, roff = ((unsigned)n0l * p.ldr + co) * 4u;
+    const unsigned ystep = (unsigned)(RPP * p.ldy) * 4u, rstep = (unsigned)(RPP * p.ldr) * 4u;
+    f32x4 rr[2][NP];
+    int tt = t;
+    unsigned ro = roff;
+    auto issue_r = [&](f32x4 (&dst)[NP], int jslab) {     // residual rows of one slab (tt / ro walk along with it)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int n = n0l + (jslab * NP + q) * RPP;
+            const bool ok = co_ok && tt >= 0 && tt < p.T && n < p.nrows && n >= win_lo && n < win_hi;
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            dst[q] = z;
+            if (ok) dst[q] = ev_bload4(rR, ro, 0);
+            tt += RPP; if (tt >= p.S - p.P) tt -= p.S;
+            ro += rstep;
+        }
+    };
+    if (has_r) issue_r(rr[0], 0);
+    ev_lds_barrier();                                 // every wave is done reading the X tile: LDS can be reused
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        if (has_r && j + 1 < TN) issue_r(rr[(j + 1) & 1], j + 1);
+        // per-wave transposition through this wave's private LDS slab (ordered by the wave's own program order)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 q4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *(f32x4*)(Es + li * ELD + i * 32 + 8 * g + 4 * lh) = q4;
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int rl = q * RPP + er;
+            const int n = n0l + (j * NP + q) * RPP;
+            f32x4 v = *(const f32x4*)(Es + rl * ELD + ec);
+            const bool ok = co_ok && t >= 0 && t < p.T && n < p.nrows && n >= win_lo && n < win_hi;
+            if constexpr (SNAKE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(sb[e], ev_sin2(v[e] * sa[e]), v[e]);
+            } else if (do_act) {
+                v[0] = fmaxf(v[0], v[0] * p.act_slope); v[1] = fmaxf(v[1], v[1] * p.act_slope);
+                v[2] = fmaxf(v[2], v[2] * p.act_slope); v[3] = fmaxf(v[3], v[3] * p.act_slope);
+            }
+            if (has_r) v += rr[j & 1][q];
+            if (ok) ev_bstore4(rY, yoff, v);
+            t += RPP; if (t >= p.S - p.P) t -= p.S;
+            yoff += ystep;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next slab overwrites Es
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PF = false, bool FULL_ACT = true, int LEAN = 0>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
@@ -281,11 +386,22 @@ __global__ __launch_bounds__(256, (BM == 64 && !PF && !FULL_ACT) ? EV_CONV_MIN_W
 
     f32x16 acc[TM][TN];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM; ++a) {
+        f32x4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bq[g] = z;
+            if constexpr (LEAN != 0) {   // bias preloaded into the accumulators: C/D row of register 4g+e is 8g + 4*half + e
+                const int c0 = m0 + wm * (TM * 32) + a * 32 + 8 * g + 4 * lh;
+                if (p.bias && c0 < p.Cout) bq[g] = *(const f32x4*)(p.bias + c0);
+            }
+        }
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = bq[r >> 2][r & 3];
+    }
 
     const int xrows = BN + p.halo_lo + p.halo_hi;
     const int srow = tid >> 3;          // staging row within a 32-row pass
@@ -409,6 +525,10 @@ __global__ __launch_bounds__(256, (BM == 64 && !PF && !FULL_ACT) ? EV_CONV_MIN_W
     } else {
     if (nact > 0) ldAp(A0, a_off(tv_first.x, 0));
     for (int ch = 0; ch < nchunks; ++ch) {
+        // Memory phases (X staging, epilogue) issue few instructions but were measured to stretch 2-3x when the other
+        // workgroups of the CU are in their MFMA loops (issue arbitration favours the older, MFMA-issuing waves): run
+        // them at raised priority so a workgroup gets back to feeding the matrix pipe sooner.
+        __builtin_amdgcn_s_setprio(3);
         if (!(p.dbg & 8)) __syncthreads();  // previous chunk's MFMAs are done with Xs (dbg 8: timing-only ablation without barriers)
         {
             // ---- stage the X tile of this k-chunk (with the optional prologue leaky-relu): all loads first
@@ -436,6 +556,7 @@ __global__ __launch_bounds__(256, (BM == 64 && !PF && !FULL_ACT) ? EV_CONV_MIN_W
             }
         }
         if (!(p.dbg & 8)) __syncthreads();
+        __builtin_amdgcn_s_setprio(0);
         if ((p.dbg & 16) && ch == 0 && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         int tap = tv_first.x;
         const float* brow = bbase + tv_first.y * EV_LDK;
@@ -474,9 +595,11 @@ __global__ __launch_bounds__(256, (BM == 64 && !PF && !FULL_ACT) ? EV_CONV_MIN_W
     }
     }   // !PF
 
+    __builtin_amdgcn_s_setprio(3);   // epilogue: see the note on memory phases above
     if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
-    conv_epilogue<TM, TN, FULL_ACT>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN == 2>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    else conv_epilogue<TM, TN, FULL_ACT>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
