@@ -294,8 +294,10 @@ void launch_cfg2(const ConvParams& p, hipStream_t st);
 //             (instruction-lean, bias preloaded into acc)
 //   compact : any flag combination without a transcendental activation (code stays I-cache resident)
 //   full    : tanh / SiLU / Mish / SnakeBeta
+inline bool lean_acc(const ConvParams& p) { return p.accum || p.div3 || p.act2_lrelu; }
 inline bool lean_ok(const ConvParams& p) {
-    return (p.act == ACT_NONE || p.act == ACT_LRELU || (p.act == ACT_SNAKE && (((size_t)p.act_a | (size_t)p.act_b) & 15) == 0)) && !p.mask1 && !p.mask2 && p.scale == 1.f && !p.accum && !p.div3 && !p.act2_lrelu &&
+    if (lean_acc(p) && (!p.R || p.act != ACT_NONE)) return false;
+    return (p.act == ACT_NONE || p.act == ACT_LRELU || (p.act == ACT_SNAKE && (((size_t)p.act_a | (size_t)p.act_b) & 15) == 0)) && !p.mask1 && !p.mask2 && p.scale == 1.f &&
            !p.Y2 && !p.rowmask && p.osplit_log2 >= 31 && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (!p.R || (p.ldr & 3) == 0) &&
            (!p.bias || ((size_t)p.bias & 15) == 0) && !(p.dbg & 4);
 }
@@ -304,6 +306,7 @@ void launch_cfg(const ConvParams& p, hipStream_t st) {
     static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
     if (!no_lean && lean_ok(p)) {
         if (p.act == ACT_SNAKE) launch_cfg2<BM, BN, WM, WN, PF, false, 2>(p, st);
+        else if (lean_acc(p)) launch_cfg2<BM, BN, WM, WN, PF, false, 3>(p, st);
         else launch_cfg2<BM, BN, WM, WN, PF, false, 1>(p, st);
     } else if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_cfg2<BM, BN, WM, WN, PF, false, 0>(p, st);
     else launch_cfg2<BM, BN, WM, WN, PF, true, 0>(p, st);
@@ -451,23 +454,31 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
+    static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
+    const int lean = no_lean ? 0 : ((e.accum || e.div3 || e.act2_lrelu) ? 3 : 1);
     if (C == 32) {
         constexpr int NT = 256;
         pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
         const size_t smem = (size_t)(NT + EV_HALO) * EV_LDK * sizeof(float);
-        hipLaunchKernelGGL((resblock_pair_kernel<1, 4>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+        if (lean == 1) hipLaunchKernelGGL((resblock_pair_kernel<1, 4, 1>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+        else if (lean == 3) hipLaunchKernelGGL((resblock_pair_kernel<1, 4, 3>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+        else hipLaunchKernelGGL((resblock_pair_kernel<1, 4, 0>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
     } else if (C == 64) {
         constexpr int NT = 128;
         pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
         const size_t xs = (size_t)(NT + EV_HALO) * EV_LDK, ys = (size_t)2 * (NT + 16) * EV_LDK;
         const size_t smem = (xs > ys ? xs : ys) * sizeof(float);
-        hipLaunchKernelGGL((resblock_pair_kernel<2, 2>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+        if (lean == 1) hipLaunchKernelGGL((resblock_pair_kernel<2, 2, 1>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+        else if (lean == 3) hipLaunchKernelGGL((resblock_pair_kernel<2, 2, 3>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+        else hipLaunchKernelGGL((resblock_pair_kernel<2, 2, 0>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
     } else if (C == 128) {
         constexpr int NT = 64;    // 4 waves = 4 channel tiles; 64 compute rows keep the 128-channel intermediate in 46 KB of LDS
         pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
         const size_t xs = (size_t)(NT + EV_HALO) * EV_LDK, ys = (size_t)4 * (NT + 16) * EV_LDK;
         const size_t smem = (xs > ys ? xs : ys) * sizeof(float);
-        hipLaunchKernelGGL((resblock_pair_kernel<4, 1>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+        if (lean == 1) hipLaunchKernelGGL((resblock_pair_kernel<4, 1, 1>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+        else if (lean == 3) hipLaunchKernelGGL((resblock_pair_kernel<4, 1, 3>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
+        else hipLaunchKernelGGL((resblock_pair_kernel<4, 1, 0>), dim3(p.ntiles), dim3(256), smem, h->stream, pp);
     } else {
         return fail(h, "launch_pair: C must be 32, 64 or 128");
     }
@@ -477,7 +488,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         const double valid_rows = (double)(g.nrows / g.S) * g.T;
         h->prof_flops += 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows;
         h->prof_launches += 1;
-        h->prof_recs.push_back({1, C, C, L1.ntaps, g.nrows, 100 + L2.ntaps, 0, 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows});
+        h->prof_recs.push_back({1, C, C, L1.ntaps, g.nrows, 100 + L2.ntaps, lean, 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows});
     }
     return 0;
 }

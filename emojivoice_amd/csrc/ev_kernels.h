@@ -87,7 +87,8 @@ __device__ __forceinline__ int2 ev_uniform(int2 v) {
     return make_int2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y));
 }
 
-__device__ __forceinline__ float ev_lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+// leaky-relu for slopes in [0, 1] (every use here): max(v, v*s) is two VALU instructions instead of compare / multiply / select
+__device__ __forceinline__ float ev_lrelu(float v, float s) { return fmaxf(v, v * s); }
 __device__ __forceinline__ float ev_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float ev_mish(float x) { return x * tanhf(ev_softplus(x)); }
 __device__ __forceinline__ float ev_silu(float x) { return x / (1.f + expf(-x)); }
@@ -260,7 +261,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
 // incremental (one modulo per lane), the per-wave LDS transposition needs no workgroup barrier after the first one,
 // and the residual rows of slab j+1 are requested before slab j's stores (vmcnt retires in order).
 // ---------------------------------------------------------------------------
-template <int TM, int TN, bool SNAKE = false>
+// MODE 1: y = lrelu?(acc) [+ R]      MODE 2: y = snake(acc)      MODE 3: y = lrelu2?((acc + R + Yold) [/ 3])  (resblock mean)
+__device__ __forceinline__ float ev_div3(float x) {   // correctly rounded x / 3 in three instructions
+    const float q = x * 0.333333343267440796f;
+    return fmaf(fmaf(-3.f, q, x), 0.333333343267440796f, q);
+}
+template <int TM, int TN, int MODE = 1>
 __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane,
                                                    int win_lo = -0x7fffffff, int win_hi = 0x7fffffff) {
     constexpr int EC = TM * 32, ELD = EC + 4, C4 = EC / 4, RPP = 64 / C4, NP = 32 / RPP;
@@ -271,6 +277,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     const __amdgpu_buffer_rsrc_t rY = ev_rsrc(p.Y), rR = ev_rsrc(p.R);
     const bool has_r = p.R != nullptr;
     const bool do_act = p.act == ACT_LRELU;
+    constexpr bool SNAKE = MODE == 2, ACC = MODE == 3;
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = sa;
     if constexpr (SNAKE) {
         if (co_ok) { sa = *(const f32x4*)(p.act_a + co); sb = *(const f32x4*)(p.act_b + co); }
@@ -282,26 +289,31 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     t -= p.P;
     unsigned yoff = ((unsigned)n0l * p.ldy + co) * 4u, roff = ((unsigned)n0l * p.ldr + co) * 4u;
     const unsigned ystep = (unsigned)(RPP * p.ldy) * 4u, rstep = (unsigned)(RPP * p.ldr) * 4u;
-    f32x4 rr[2][NP];
+    f32x4 rr[2][NP], ra[ACC ? 2 : 1][ACC ? NP : 1];
     int tt = t;
-    unsigned ro = roff;
-    auto issue_r = [&](f32x4 (&dst)[NP], int jslab) {     // residual rows of one slab (tt / ro walk along with it)
+    unsigned ro = roff, ao = yoff;
+    auto issue_r = [&](int set, int jslab) {     // residual (and running-sum) rows of one slab (tt / ro / ao walk along with it)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
             const int n = n0l + (jslab * NP + q) * RPP;
             const bool ok = co_ok && tt >= 0 && tt < p.T && n < p.nrows && n >= win_lo && n < win_hi;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            dst[q] = z;
-            if (ok) dst[q] = ev_bload4(rR, ro, 0);
+            rr[set][q] = z;
+            if (ok) rr[set][q] = ev_bload4(rR, ro, 0);
+            if constexpr (ACC) {
+                ra[set][q] = z;
+                if (ok && p.accum) ra[set][q] = ev_bload4(rY, ao, 0);
+                ao += ystep;
+            }
             tt += RPP; if (tt >= p.S - p.P) tt -= p.S;
             ro += rstep;
         }
     };
-    if (has_r) issue_r(rr[0], 0);
+    if (has_r) issue_r(0, 0);
     ev_lds_barrier();                                 // every wave is done reading the X tile: LDS can be reused
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        if (has_r && j + 1 < TN) issue_r(rr[(j + 1) & 1], j + 1);
+        if (has_r && j + 1 < TN) issue_r((j + 1) & 1, j + 1);
         // per-wave transposition through this wave's private LDS slab (ordered by the wave's own program order)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -325,6 +337,14 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
                 v[2] = fmaxf(v[2], v[2] * p.act_slope); v[3] = fmaxf(v[3], v[3] * p.act_slope);
             }
             if (has_r) v += rr[j & 1][q];
+            if constexpr (ACC) {
+                v += ra[j & 1][q];
+                if (p.div3) { v[0] = ev_div3(v[0]); v[1] = ev_div3(v[1]); v[2] = ev_div3(v[2]); v[3] = ev_div3(v[3]); }
+                if (p.act2_lrelu) {
+                    v[0] = fmaxf(v[0], v[0] * p.act2_slope); v[1] = fmaxf(v[1], v[1] * p.act2_slope);
+                    v[2] = fmaxf(v[2], v[2] * p.act2_slope); v[3] = fmaxf(v[3], v[3] * p.act2_slope);
+                }
+            }
             if (ok) ev_bstore4(rY, yoff, v);
             t += RPP; if (t >= p.S - p.P) t -= p.S;
             yoff += ystep;
@@ -598,7 +618,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     __builtin_amdgcn_s_setprio(3);   // epilogue: see the note on memory phases above
     if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
-    if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN == 2>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     else conv_epilogue<TM, TN, FULL_ACT>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 }
@@ -623,8 +643,9 @@ struct PairParams {
     int out_rows;                  // NT - 2*h2
 };
 
-template <int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp) {
+// (LDS admits 3 / 5 / 3 workgroups per CU for C = 32 / 64 / 128: keep the register allocation from going below that)
+template <int WAVES_M, int WAVES_N, int LEAN = 0>
+__global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kernel(const PairParams pp) {
     constexpr int TM = 1, TN = 2;
     constexpr int NT = WAVES_N * TN * 32;               // compute rows per workgroup
     constexpr int NCH = WAVES_M;                        // 32-channel chunks (C = 32 * WAVES_M)
@@ -661,7 +682,8 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp)
     f32x4 A0[TM], A1[TM], B0[TN], B1[TN];
 
     // one conv phase: K loop over NCH chunks x taps with the A/B fragment pipeline of conv_gemm_kernel
-    auto phase = [&](const float* Wf, const int2* tl, int nact, auto&& chunk_base) {
+    // (the accumulators start from the layer's bias when `binit` is given: C/D register 4g+e is channel 8g + 4*half + e)
+    auto phase = [&](const float* Wf, const int2* tl, int nact, const float* binit, auto&& chunk_base) {
         const __amdgpu_buffer_rsrc_t rW = ev_rsrc(Wf);
         auto a_off = [&](int tap, int kg8) -> unsigned { return (unsigned)(((tap * MT32 + wm) * KG8 + kg8) * 1024); };
         auto ldAp = [&](f32x4 (&dst)[TM], unsigned aoff) { dst[0] = ev_bload4(rW, wlane, aoff); };
@@ -676,10 +698,18 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp)
                 for (int j = 0; j < TN; ++j)
                     acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s4], b[j][s4], acc[0][j], 0, 0, 0);
         };
+        {
+            f32x4 bq[4];
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+            for (int g = 0; g < 4; ++g) {
+                f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                bq[g] = binit ? *(const f32x4*)(binit + wm * 32 + 8 * g + 4 * lh) : z;
+            }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][b][r] = 0.f;
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][b][r] = bq[r >> 2][r & 3];
+        }
         const int2 tv_first = ev_uniform(tl[0]);
         ldAp(A0, a_off(tv_first.x, 0));
         for (int ch = 0; ch < NCH; ++ch) {
@@ -720,7 +750,7 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp)
 
     // ---------------- phase 1: c1 over lrelu(x), X tile rows [g0 - h1, g0 + NT + h1) staged per 32-channel chunk
     const int xrows = NT + 2 * pp.h1;
-    phase(pp.W1, pp.taplist1, pp.ntaps1, [&](int ch) -> const float* {
+    phase(pp.W1, pp.taplist1, pp.ntaps1, pp.b1, [&](int ch) -> const float* {
         __syncthreads();
         const int c = ch * EV_BK + sc4;
         f32x4 xv[XPASS];
@@ -747,20 +777,17 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp)
     // ---------------- y1 = lrelu(c1 + b1), zero outside the utterance, into LDS [chunk = wm][row + h2][channel]
     __syncthreads();                                    // every wave is done reading Xs
     {
-        f32x4 b1v[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) b1v[g] = *(const f32x4*)(pp.b1 + wm * 32 + 8 * g + 4 * lh);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int r = wn * (TN * 32) + j * 32 + li;
             const int n = g0 + r;
             const int t = (n >= 0 && n < p.nrows) ? (n % p.S) - p.P : -1;
-            const bool inside = t >= 0 && t < p.T;
+            const float inside = (t >= 0 && t < p.T) ? 1.f : 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = inside ? ev_lrelu(acc[0][j][4 * g + e] + b1v[g][e], pp.mid_slope) : 0.f;
+                for (int e = 0; e < 4; ++e) v[e] = ev_lrelu(acc[0][j][4 * g + e], pp.mid_slope) * inside;
                 *(f32x4*)(Ys + (wm * YROWS + r + pp.h2) * EV_LDK + 8 * g + 4 * lh) = v;
             }
         }
@@ -776,12 +803,13 @@ __global__ __launch_bounds__(256) void resblock_pair_kernel(const PairParams pp)
     __syncthreads();
 
     // ---------------- phase 2: c2 over the LDS-resident y1 (tap i reads rows r + i)
-    phase(p.W, p.taplist, p.ntaps, [&](int ch) -> const float* {
+    phase(p.W, p.taplist, p.ntaps, LEAN ? p.bias : nullptr, [&](int ch) -> const float* {
         return Ys + (ch * YROWS + wn * (TN * 32) + li + pp.h2) * EV_LDK + 4 * lh;
     });
 
     // ---------------- epilogue: + b2 + x (residual re-read, L2-hot), optional running resblock mean, window [n0, n0 + out_rows)
-    conv_epilogue<TM, TN, false>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
+    if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
+    else conv_epilogue<TM, TN, false>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
 }
 
 // ---------------------------------------------------------------------------
