@@ -286,7 +286,7 @@ int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** o
 static int g_xrows_halo = EV_HALO;   // halo rows of the layer being launched (LDS is sized for BN + halo, not BN + EV_HALO)
 static int g_dbg_wgs_per_cu = 0;   // tools/conv_bench.py: cap workgroups per CU by over-allocating LDS (0 = off)
 
-template <int BM, int BN, int WM, int WN, bool PF, bool FULL, int LEAN>
+template <int BM, int BN, int WM, int WN, bool PF, bool FULL, int LEAN, int KB = 1>
 void launch_cfg2(const ConvParams& p, hipStream_t st);
 
 // Dispatch on the epilogue flavour:
@@ -301,25 +301,29 @@ inline bool lean_ok(const ConvParams& p) {
            !p.Y2 && !p.rowmask && p.osplit_log2 >= 31 && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (!p.R || (p.ldr & 3) == 0) &&
            (!p.bias || ((size_t)p.bias & 15) == 0) && !(p.dbg & 4);
 }
+static int g_kb = 1;   // k-chunks per stage for the launch being issued (see conv_gemm_kernel: KB)
 template <int BM, int BN, int WM, int WN, bool PF = false>
 void launch_cfg(const ConvParams& p, hipStream_t st) {
     static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
+    const bool kb2 = !PF && g_kb == 2;
     if (!no_lean && lean_ok(p)) {
-        if (p.act == ACT_SNAKE) launch_cfg2<BM, BN, WM, WN, PF, false, 2>(p, st);
-        else if (lean_acc(p)) launch_cfg2<BM, BN, WM, WN, PF, false, 3>(p, st);
-        else launch_cfg2<BM, BN, WM, WN, PF, false, 1>(p, st);
-    } else if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_cfg2<BM, BN, WM, WN, PF, false, 0>(p, st);
-    else launch_cfg2<BM, BN, WM, WN, PF, true, 0>(p, st);
+        if (p.act == ACT_SNAKE) { if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 2, 2>(p, st); else launch_cfg2<BM, BN, WM, WN, PF, false, 2>(p, st); }
+        else if (lean_acc(p)) { if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 3, 2>(p, st); else launch_cfg2<BM, BN, WM, WN, PF, false, 3>(p, st); }
+        else { if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 1, 2>(p, st); else launch_cfg2<BM, BN, WM, WN, PF, false, 1>(p, st); }
+    } else if (p.act == ACT_NONE || p.act == ACT_LRELU) {
+        if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 0, 2>(p, st); else launch_cfg2<BM, BN, WM, WN, PF, false, 0>(p, st);
+    } else launch_cfg2<BM, BN, WM, WN, PF, true, 0>(p, st);
 }
 
-template <int BM, int BN, int WM, int WN, bool PF, bool FULL, int LEAN>
+template <int BM, int BN, int WM, int WN, bool PF, bool FULL, int LEAN, int KB>
 void launch_cfg2(const ConvParams& p, hipStream_t st) {
     // LDS holds the X tile during the K loop and, afterwards, one transposed 32-frame slab per wave for the epilogue
-    const size_t xs = (size_t)(BN + ((g_xrows_halo + 7) & ~7)) * EV_LDK;
+    const size_t xs = (size_t)(BN + ((g_xrows_halo + 7) & ~7)) * (32 * KB + 4);
     constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4);
     size_t smem = (xs > es ? xs : es) * sizeof(float);
-    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); }
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; }
+    if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
 int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {
@@ -374,7 +378,12 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         if (env && *env) cfg = atoi(env);
     }
     g_dbg_wgs_per_cu = 0;
-    if (e.force_cfg >= 0) { cfg = e.force_cfg % 100; g_dbg_wgs_per_cu = e.force_cfg / 100; }
+    g_kb = 1;
+    {   // A/B override: EV_KB=<1|2> forces the k-chunks per stage of every conv launch
+        static const char* kenv = getenv("EV_KB");
+        if (kenv && *kenv) g_kb = atoi(kenv) == 2 ? 2 : 1;
+    }
+    if (e.force_cfg >= 0) { cfg = e.force_cfg % 100; g_dbg_wgs_per_cu = (e.force_cfg / 100) % 10; g_kb = e.force_cfg >= 1000 ? 2 : 1; }
     g_xrows_halo = L.halo_lo + L.halo_hi;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
@@ -388,6 +397,10 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         const int slots = cfg == 0 ? 3 : ((cfg == 1 || cfg == 5 || cfg == 7) ? 4 : ((cfg == 6 || cfg == 8) ? 5 : 3));
         const long wgs = (cfg == 5 || cfg == 7) ? (long)((L.Cout + 63) / 64) * ((g.nrows + 191) / 192) : (cfg == 6 || cfg == 8) ? (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64) : cfg == 0 ? (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) : (cfg == 1 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) : (long)((L.Cout + 31) / 32) * ((g.nrows + 255) / 256));
         p.stagger_slots = (wgs >= 256L * slots * 3) ? slots : 0;
+        {   // experiment: EV_PHASE=<q> staggers the co-resident workgroups of single-round launches by q/4 MFMA phases each
+            static const char* penv = getenv("EV_PHASE");
+            if (penv && *penv && wgs <= 256L * 6) p.stagger_slots = -atoi(penv);
+        }
         if (e.stagger >= 0) p.stagger_slots = e.stagger;
         static const char* senv = getenv("EV_STAGGER");
         if (senv && *senv) p.stagger_slots = atoi(senv) ? p.stagger_slots : 0;

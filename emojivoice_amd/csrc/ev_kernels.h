@@ -353,14 +353,20 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool PF = false, bool FULL_ACT = true, int LEAN = 0>
+// KB = 32-channel k-chunks staged per barrier pair (LDS row = 32*KB + 4 floats).  KB = 2 halves the number of
+// stage / barrier episodes — what the 1x1 and k=3 layers need (a 1x1 conv has only 4 k-groups = 32 MFMAs per wave
+// between two barrier pairs at KB = 1); wide-halo layers (k = 11, d = 5) already run 352 MFMAs per chunk and keep KB = 1
+// for its smaller LDS tile (more workgroups per CU).  The accumulation order (chunk, tap, k-group) is the same for both.
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool PF = false, bool FULL_ACT = true, int LEAN = 0, int KB = 1>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
+    constexpr int LDK = 32 * KB + 4;                   // LDS row stride (floats): 36 / 68 are both conflict-free for ds_read_b128
+    static_assert(!PF || KB == 1, "the register-prefetch build stages one 32-channel chunk at a time");
     static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
     static_assert(TM >= 1 && TN >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Xs = smem;                                  // [(BN + EV_HALO)][EV_LDK]
+    float* Xs = smem;                                  // [(BN + EV_HALO)][LDK]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -396,7 +402,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     // then its memory-bound epilogues at the same time.  Delaying the k-th co-resident workgroup of the FIRST wave of
     // workgroups by k/slots of one tile time puts (and keeps) them out of phase: one streams its epilogue while the
     // others feed the matrix pipe.
-    if (p.stagger_slots > 1 && (int)blockIdx.x < 256 * p.stagger_slots) {
+    if (p.stagger_slots < 0) {
+        // single-round launches: every CU holds its 2-5 workgroups from t = 0 to the end, all in the same phase (they
+        // stage together, then compete for the matrix pipe together).  Offsetting co-resident workgroup k by k MFMA
+        // phases (one k-chunk of one wave) interleaves them: one feeds the pipe while the others stage.
+        const int slot = blockIdx.x >> 8;
+        const long wait = (long)nact * (16L * TM * TN * 64) * slot * (-p.stagger_slots) / 4;
+        const long long t0 = __builtin_amdgcn_s_memtime();
+        while ((long)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(8);
+    } else if (p.stagger_slots > 1 && (int)blockIdx.x < 256 * p.stagger_slots) {
         const int slot = blockIdx.x >> 8;
         const long tile_cycles = (long)(p.Kpad / EV_BK) * nact * (16L * TM * TN * 64) * p.stagger_slots;
         const long wait = tile_cycles * slot / p.stagger_slots;
@@ -424,8 +438,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     }
 
     const int xrows = BN + p.halo_lo + p.halo_hi;
-    const int srow = tid >> 3;          // staging row within a 32-row pass
-    const int sc4 = (tid & 7) * 4;      // staging column (floats)
+    constexpr int TPR = 8 * KB, RPS = 256 / TPR;   // staging: threads per row, rows per pass
+    const int srow = tid / TPR;         // staging row within a pass
+    const int sc4 = (tid % TPR) * 4;    // staging column (floats)
     const int nchunks = p.Kpad / EV_BK;
 
     // A operand (weights) never touches LDS: the host packs them in MFMA-fragment order
@@ -433,7 +448,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     // so one global_load_dwordx4 per wave reads a contiguous 1 KiB (L2-resident) fragment feeding four MFMAs per
     // 32-row tile.  Fragments are prefetched one k-group ahead, across taps and k-chunks, so the waves of a
     // workgroup only meet at the two barriers around each X-tile (activation) stage.
-    constexpr int XPASS = (BN + EV_HALO) / 32;
+    constexpr int XPASS = (BN + EV_HALO) / RPS;
+    constexpr int XG = XPASS > 8 ? 8 : XPASS;      // passes per load batch (bounds the registers in flight)
     const int mt32 = (m0 + wm * (TM * 32)) >> 5;          // first 32-row tile of this wave
     const int MT32 = p.Mpad >> 5, KG8 = p.Kpad >> 3;
     const __amdgpu_buffer_rsrc_t rW = ev_rsrc(p.W), rX = ev_rsrc(p.X);
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     };
     auto ldB = [&](f32x4 (&dst)[TN], const float* brow, int kg) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) dst[j] = *(const f32x4*)(brow + j * 32 * EV_LDK + kg * 8);
+        for (int j = 0; j < TN; ++j) dst[j] = *(const f32x4*)(brow + j * 32 * LDK + kg * 8);
     };
     auto mma = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
 #pragma unroll
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s4], b[j][s4], acc[i][j], 0, 0, 0);
     };
-    const float* bbase = Xs + (wn * (TN * 32) + li + p.halo_lo) * EV_LDK + 4 * lh;
+    const float* bbase = Xs + (wn * (TN * 32) + li + p.halo_lo) * LDK + 4 * lh;
     const int2 tv_first = (nact > 0) ? ev_uniform(tl[0]) : make_int2(0, 0);
     if constexpr (PF) {
         // ---- software-pipelined X staging.  The X tile of chunk c+1 is loaded into registers while chunk c's MFMAs
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                     v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
                     v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
                 }
-                if (r < xrows) *(f32x4*)(Xs + r * EV_LDK + sc4) = v;
+                if (r < xrows) *(f32x4*)(Xs + r * LDK + sc4) = v;
             }
         };
         f32x4 A2[TM], A3[TM];
@@ -509,14 +525,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             __syncthreads();
             if (ch + 1 < nchunks) x_load(ch + 1);
             int tap = tv_first.x;
-            const float* brow = bbase + tv_first.y * EV_LDK;
+            const float* brow = bbase + tv_first.y * LDK;
             ldB(B0, brow, 0);
             int2 tv_pre = tl[nact > 1 ? 1 : 0];                 // raw (vector) load; made uniform at its use one tap later
             for (int ti = 0; ti < nact; ++ti) {
                 const bool last_tap = (ti + 1 == nact);
                 const int2 ntv = last_tap ? tv_first : ev_uniform(tv_pre);
                 tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
-                const float* nbrow = bbase + ntv.y * EV_LDK;
+                const float* nbrow = bbase + ntv.y * LDK;
                 const unsigned ap = a_off(tap, ch * 4);
                 const unsigned nap = a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4);
                 const bool have_next = !(last_tap && ch + 1 == nchunks);
@@ -544,50 +560,62 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         }
     } else {
     if (nact > 0) ldAp(A0, a_off(tv_first.x, 0));
+    unsigned long long ts0 = 0, acc_st = 0, acc_b1 = 0;   // dbg 2 (+16): accumulated stage / first-barrier time of this wave
     for (int ch = 0; ch < nchunks; ++ch) {
         // Memory phases (X staging, epilogue) issue few instructions but were measured to stretch 2-3x when the other
         // workgroups of the CU are in their MFMA loops (issue arbitration favours the older, MFMA-issuing waves): run
         // them at raised priority so a workgroup gets back to feeding the matrix pipe sooner.
+        const int sub = ch & (KB - 1);
+        if (sub == 0) {
         __builtin_amdgcn_s_setprio(3);
+        if (p.dbg & 2) ts0 = __builtin_amdgcn_s_memrealtime();
         if (!(p.dbg & 8)) __syncthreads();  // previous chunk's MFMAs are done with Xs (dbg 8: timing-only ablation without barriers)
+        if (p.dbg & 2) { const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(); acc_b1 += t1 - ts0; }
         {
-            // ---- stage the X tile of this k-chunk (with the optional prologue leaky-relu): all loads first
+            // ---- stage the X tile of these KB k-chunks (with the optional prologue leaky-relu): all loads of a batch first
             const int c = ch * EV_BK + sc4;
             const bool cok = c < p.Cin;
             const unsigned xcol = (unsigned)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1));
-            f32x4 xv[XPASS];
 #pragma unroll
-            for (int q = 0; q < XPASS; ++q) {
-                const int r = q * 32 + srow;
-                const int gr = n0 - p.halo_lo + r;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cok && r < xrows && gr >= 0 && gr < p.nrows && !(p.dbg & 1)) v = ev_bload4(rX, ((unsigned)gr * p.ldx + xcol) * 4u, 0);
-                xv[q] = v;
-            }
+            for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                if (q0 * RPS >= xrows) break;
+                f32x4 xv[XG];
 #pragma unroll
-            for (int q = 0; q < XPASS; ++q) {
-                const int r = q * 32 + srow;
-                f32x4 v = xv[q];
-                if (p.pro_lrelu) {
-                    v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
-                    v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                for (int q = 0; q < XG; ++q) {
+                    const int r = (q0 + q) * RPS + srow;
+                    const int gr = n0 - p.halo_lo + r;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (cok && r < xrows && gr >= 0 && gr < p.nrows && !(p.dbg & 1)) v = ev_bload4(rX, ((unsigned)gr * p.ldx + xcol) * 4u, 0);
+                    xv[q] = v;
                 }
-                if (r < xrows) *(f32x4*)(Xs + r * EV_LDK + sc4) = v;
+#pragma unroll
+                for (int q = 0; q < XG; ++q) {
+                    const int r = (q0 + q) * RPS + srow;
+                    f32x4 v = xv[q];
+                    if (p.pro_lrelu) {
+                        v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                        v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                    }
+                    if (r < xrows) *(f32x4*)(Xs + r * LDK + sc4) = v;
+                }
             }
         }
         if (!(p.dbg & 8)) __syncthreads();
         __builtin_amdgcn_s_setprio(0);
-        if ((p.dbg & 16) && ch == 0 && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        if (p.dbg & 2) acc_st += __builtin_amdgcn_s_memrealtime() - ts0;
+        }
+        const float* bsub = bbase + sub * 32;
+        if ((p.dbg & 18) == 16 && ch == 0 && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         int tap = tv_first.x;
-        const float* brow = bbase + tv_first.y * EV_LDK;
-        ldB(B0, brow, 0);
-        int2 tv_pre = tl[nact > 1 ? 1 : 0];                 // raw (vector) load; made uniform at its use one tap later            // tap list entries are fetched one tap ahead of their use
+        const float* brow = bsub + tv_first.y * LDK;
+        if (sub == 0) ldB(B0, brow, 0);                     // (later sub-chunks: prefetched by the last tap of the previous one)
+        int2 tv_pre = tl[nact > 1 ? 1 : 0];                 // raw (vector) load; made uniform at its use one tap later
         for (int ti = 0; ti < nact; ++ti) {
             const bool last_tap = (ti + 1 == nact);
             const int2 ntv = last_tap ? tv_first : ev_uniform(tv_pre);
             tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
             const int ntap = ntv.x;
-            const float* nbrow = bbase + ntv.y * EV_LDK;
+            const float* nbrow = bsub + ntv.y * LDK;
             const unsigned ap = a_off(tap, ch * 4);                                // k-groups of this tap: +1 KiB each
             const unsigned nap = a_off(ntap, last_tap ? ch * 4 + 4 : ch * 4);
             const bool have_next = !(last_tap && ch + 1 == nchunks);
@@ -607,16 +635,21 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             __builtin_amdgcn_sched_barrier(0);
             if (have_next) ldAp(A0, nap);
             if (!last_tap) ldB(B0, nbrow, 0);
+            else if (KB > 1 && sub + 1 < KB && ch + 1 < nchunks) ldB(B0, nbrow + 32, 0);   // next sub-chunk is already in LDS
             __builtin_amdgcn_sched_barrier(0);
             mma(A1, B1);
             __builtin_amdgcn_sched_barrier(0);
             tap = ntap; brow = nbrow;
         }
     }
+    if ((p.dbg & 18) == 18 && threadIdx.x == 0) {   // stamps 1 / 2 become start + accumulated stage time / first-barrier wait
+        p.stamps[4 * blockIdx.x + 1] = p.stamps[4 * blockIdx.x] + acc_st;
+        p.stamps[4 * blockIdx.x + 2] = p.stamps[4 * blockIdx.x] + acc_b1;
+    }
     }   // !PF
 
     __builtin_amdgcn_s_setprio(3);   // epilogue: see the note on memory phases above
-    if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    if ((p.dbg & 18) == 16 && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
     if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     else conv_epilogue<TM, TN, FULL_ACT>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
