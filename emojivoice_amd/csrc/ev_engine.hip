@@ -70,6 +70,7 @@ struct VocoderW {
     ConvLayer pre, post, ups[4];
     ConvLayer c1[12][3], c2[12][3];
     int ch[5];  // channels per level: 512, 256, 128, 64, 32
+    float* post_w = nullptr; float post_b = 0.f; int post_k = 0;   // conv_post as [K][C] for conv_post_kernel
 };
 
 }  // namespace
@@ -896,6 +897,13 @@ int ev_load_vocoder(ev_handle* h, const float* blob, const ev_tensor_index* inde
     if (!pw || !pb || !qw || !qb) return 1;
     REQ(pack_conv(h, v.pre, *pw, pb, 1));
     REQ(pack_conv(h, v.post, *qw, qb, 1));
+    {   // conv_post_kernel's copy: (1, C, K) -> [K][C]
+        const int C = (int)qw->shape[1], K = (int)qw->shape[2];
+        std::vector<float> wt((size_t)K * C);
+        for (int c = 0; c < C; ++c) for (int k = 0; k < K; ++k) wt[(size_t)k * C + c] = qw->p[(size_t)c * K + k];
+        REQ(dev_upload(h, wt, &v.post_w));
+        v.post_b = qb->p[0]; v.post_k = K;
+    }
     v.ch[0] = (int)pw->shape[0];
     for (int i = 0; i < 4; ++i) {
         char nm[64];
@@ -1037,12 +1045,20 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
         xin = v.XS[l];
         cin = C;
     }
-    {   // conv_post + tanh, then strip the pads into (B, 256 T)
-        Epi e; e.act = ACT_TANH;
-        if (launch_conv(h, w.post, v.XS[4], w.ch[4], v.T1[4], 1, v.g[4], e)) return 1;
-        const size_t total = (size_t)B * v.g[4].T;
-        hipLaunchKernelGGL(strip_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, (const float*)v.T1[4], d_wav, v.g[4].T, v.g[4].S, v.g[4].P, total);
-        HIPCHK(h, hipGetLastError());
+    {   // conv_post + tanh straight into (B, 256 T)
+        const Geom& g4 = v.g[4];
+        if (w.ch[4] == 32 && w.post_k == 7 && w.post_w && g4.P >= 3) {
+            const int tiles = (g4.T + 255) / 256;
+            hipLaunchKernelGGL((conv_post_kernel<32, 7>), dim3((unsigned)(B * tiles)), dim3(256), 0, h->stream, (const float*)v.XS[4], (const float*)w.post_w,
+                               w.post_b, d_wav, g4.T, g4.S, g4.P);
+            HIPCHK(h, hipGetLastError());
+        } else {   // other channel / tap counts: the generic conv + a strip pass
+            Epi e; e.act = ACT_TANH;
+            if (launch_conv(h, w.post, v.XS[4], w.ch[4], v.T1[4], 1, g4, e)) return 1;
+            const size_t total = (size_t)B * g4.T;
+            hipLaunchKernelGGL(strip_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, (const float*)v.T1[4], d_wav, g4.T, g4.S, g4.P, total);
+            HIPCHK(h, hipGetLastError());
+        }
     }
     return 0;
 }

@@ -89,8 +89,14 @@ __device__ __forceinline__ int2 ev_uniform(int2 v) {
 
 // leaky-relu for slopes in [0, 1] (every use here): max(v, v*s) is two VALU instructions instead of compare / multiply / select
 __device__ __forceinline__ float ev_lrelu(float v, float s) { return fmaxf(v, v * s); }
-__device__ __forceinline__ float ev_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
-__device__ __forceinline__ float ev_mish(float x) { return x * tanhf(ev_softplus(x)); }
+// mish(x) = x * tanh(softplus(x)) (decoder.py:41-43).  With w = e^x:  tanh(log(1 + w)) = (w^2 + 2w) / (w^2 + 2w + 2), so one
+// exp and one division replace exp + log1p + tanh (the GroupNorm+Mish pass over 8.5 M elements per launch was VALU-bound
+// on ocml's log1pf / tanhf).  torch's softplus threshold (x > 20 -> softplus = x, tanh = 1 in fp32) is kept.
+__device__ __forceinline__ float ev_mish(float x) {
+    const float w = expf(fminf(x, 20.f));
+    const float n = w * (w + 2.f);
+    return x > 20.f ? x : x * __fdividef(n, n + 2.f);
+}
 __device__ __forceinline__ float ev_silu(float x) { return x / (1.f + expf(-x)); }
 
 // sin^2(u) in ~17 VALU instructions (the SnakeBeta feed-forward epilogue evaluates 34 M of these per launch; ocml's
@@ -1203,6 +1209,40 @@ __global__ void time_sinusoid_kernel(const float* tvals, float* emb, int nt, int
     float a = (scale * tvals[i]) * f;
     emb[(size_t)i * dim + k] = sinf(a);
     emb[(size_t)i * dim + half + k] = cosf(a);
+}
+
+// conv_post (hifigan/models.py:195-196: Conv1d(C, 1, K, padding = K/2) + tanh) straight into the (B, T) waveform.  One
+// output channel makes this a sliding dot product, not a GEMM: a 32-row MFMA tile would waste 31/32 of the matrix
+// pipe and the launch was latency-bound at ~0.65 TB/s.  Here a workgroup stages 256 + K - 1 frames x C channels in LDS
+// (coalesced 16-byte loads, row stride C + 4: conflict-free ds_read_b128 with one frame per lane) and each lane
+// accumulates its frame's K*C products; weights are wave-uniform scalar loads.  HBM-bound: one read of the C-channel
+// activations, one write of the waveform, pads stripped on the way out (no separate strip pass).
+template <int C, int K>
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ X, const float* __restrict__ W /*[K][C]*/, float bias,
+                                                        float* __restrict__ wav, int T, int S, int P) {
+    constexpr int LD = C + 4, ROWS = 256 + K - 1, C4 = C / 4;
+    __shared__ __attribute__((aligned(16))) float xs[ROWS * LD];
+    const int tid = threadIdx.x;
+    const int tiles = (T + 255) / 256;
+    const int b = blockIdx.x / tiles, t0 = (blockIdx.x % tiles) * 256;
+    const size_t row0 = (size_t)b * S + P + t0 - K / 2;          // P >= K/2: the pad rows are the conv's zero padding
+    for (int i = tid; i < ROWS * C4; i += 256) {
+        const int r = i / C4, c4 = (i % C4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (t0 - K / 2 + r < T + P) v = *(const f32x4*)(X + (row0 + r) * C + c4);
+        *(f32x4*)(xs + r * LD + c4) = v;
+    }
+    __syncthreads();
+    float acc = bias;
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) {
+            const f32x4 v = *(const f32x4*)(xs + (tid + k) * LD + c4 * 4);
+            const float* w = W + k * C + c4 * 4;
+            acc = fmaf(v[0], w[0], acc); acc = fmaf(v[1], w[1], acc); acc = fmaf(v[2], w[2], acc); acc = fmaf(v[3], w[3], acc);
+        }
+    if (t0 + tid < T) wav[(size_t)b * T + t0 + tid] = tanhf(acc);
 }
 
 // frame-major (rows, C) -> flat waveform (B, T): C == 1 with pads stripped
