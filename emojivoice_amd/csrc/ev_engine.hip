@@ -140,6 +140,7 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
     if (bias) { if (dev_upload(h, *bias, &L.bias)) return 1; }
     // per-tile compact lists of non-zero taps (polyphase transposed convs have all-zero (phase, tap) slabs)
     const int bms[3] = {128, 64, 32};
+    const int plane_bytes = (L.Mpad / 32) * (L.Kpad / 8) * 1024;   // tap-list entries carry the byte offset of the tap's weight plane
     std::vector<std::vector<int2>> lists[3];
     L.sparse_taps = false;
     for (int k = 0; k < 3; ++k) {
@@ -153,7 +154,7 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                     const float* row = &Wh[((size_t)tap * L.Mpad + m) * L.Kpad];
                     for (int c = 0; c < L.Kpad; ++c) if (row[c] != 0.f) { nz = true; break; }
                 }
-                if (nz) lists[k][t].push_back(make_int2(tap, L.off[tap]));
+                if (nz) lists[k][t].push_back(make_int2(tap * plane_bytes, L.off[tap]));
                 else if (t * BM < L.Cout) L.sparse_taps = true;
             }
     }
@@ -161,7 +162,7 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
         const int mt = L.Mpad / bms[k];
         if (!L.sparse_taps) {   // dense: one shared row holding every tap
             std::vector<int2> row(EV_MAX_TAPS, make_int2(0, 0));
-            for (int tap = 0; tap < L.ntaps; ++tap) row[tap] = make_int2(tap, L.off[tap]);
+            for (int tap = 0; tap < L.ntaps; ++tap) row[tap] = make_int2(tap * plane_bytes, L.off[tap]);
             if (dev_upload(h, row, &L.taplist[k])) return 1;
             L.nact[k] = nullptr;
         } else {

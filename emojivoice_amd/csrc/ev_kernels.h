@@ -88,7 +88,11 @@ __device__ __forceinline__ int2 ev_uniform(int2 v) {
 }
 
 // leaky-relu for slopes in [0, 1] (every use here): max(v, v*s) is two VALU instructions instead of compare / multiply / select
-__device__ __forceinline__ float ev_lrelu(float v, float s) { return fmaxf(v, v * s); }
+__device__ __forceinline__ float ev_lrelu(float v, float s) {
+    float r;   // plain v_max_f32: fmaxf() makes hipcc quiet a possible sNaN first (one extra v_max v, v, v per element)
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(v * s));
+    return r;
+}
 // mish(x) = x * tanh(softplus(x)) (decoder.py:41-43).  With w = e^x:  tanh(log(1 + w)) = (w^2 + 2w) / (w^2 + 2w + 2), so one
 // exp and one division replace exp + log1p + tanh (the GroupNorm+Mish pass over 8.5 M elements per launch was VALU-bound
 // on ocml's log1pf / tanhf).  torch's softplus threshold (x > 20 -> softplus = x, tanh = 1 in fp32) is kept.
@@ -460,8 +464,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const int MT32 = p.Mpad >> 5, KG8 = p.Kpad >> 3;
     const __amdgpu_buffer_rsrc_t rW = ev_rsrc(p.W), rX = ev_rsrc(p.X);
     const unsigned wlane = (unsigned)lane * 16u;           // per-lane byte offset inside a 1 KiB fragment
-    auto a_off = [&](int tap, int kg8) -> unsigned {       // byte offset (wave-uniform) of row-tile mt32's fragment at k-group kg8
-        return (unsigned)(((tap * MT32 + mt32) * KG8 + kg8) * 1024);
+    const unsigned wbase = (unsigned)(mt32 * KG8) * 1024u;
+    (void)MT32;
+    auto a_off = [&](int tap_bytes, int kg8) -> unsigned {  // byte offset (wave-uniform) of row-tile mt32's fragment at k-group kg8;
+        return (unsigned)tap_bytes + wbase + (unsigned)kg8 * 1024u;   // the tap list carries tap * (Mpad/32) * (Kpad/8) * 1 KiB
     };
     // Two statically named fragment sets (A0/B0 for even k-groups, A1/B1 for odd ones): the loads for k-group g+1
     // are issued before the MFMAs of k-group g and first touched one k-group later — no register copies, so the
@@ -566,6 +572,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         }
     } else {
     if (nact > 0) ldAp(A0, a_off(tv_first.x, 0));
+    unsigned xoff[XPASS];   // byte offset of this lane's 16 bytes in staging pass q (chunk 0); rows outside the tensor -> pad row 0 (zeros)
+#pragma unroll
+    for (int q = 0; q < XPASS; ++q) {
+        const int gr = n0 - p.halo_lo + q * RPS + srow;
+        xoff[q] = ((gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
+    }
     unsigned long long ts0 = 0, acc_st = 0, acc_b1 = 0;   // dbg 2 (+16): accumulated stage / first-barrier time of this wave
     for (int ch = 0; ch < nchunks; ++ch) {
         // Memory phases (X staging, epilogue) issue few instructions but were measured to stretch 2-3x when the other
@@ -578,26 +590,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         if (!(p.dbg & 8)) __syncthreads();  // previous chunk's MFMAs are done with Xs (dbg 8: timing-only ablation without barriers)
         if (p.dbg & 2) { const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(); acc_b1 += t1 - ts0; }
         {
-            // ---- stage the X tile of these KB k-chunks (with the optional prologue leaky-relu): all loads of a batch first
-            const int c = ch * EV_BK + sc4;
-            const bool cok = c < p.Cin;
-            const unsigned xcol = (unsigned)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1));
+            // ---- stage the X tile of these KB k-chunks (with the optional prologue leaky-relu): all loads of a batch first.
+            // No per-chunk address arithmetic: the per-pass row offsets are fixed for the tile (xoff), the chunk's column
+            // base is a scalar (soffset), and rows outside the tensor read the all-zero pad row 0 instead of being masked.
+            const int c0 = ch * EV_BK;
+            const unsigned soff = ((unsigned)(c0 >> p.isplit_log2) * p.isstride + (unsigned)(c0 & ((1 << p.isplit_log2) - 1))) * 4u;
+            const bool ctail = (c0 + 32 * KB > p.Cin);       // uniform: only the last chunk of a Cin that is not a multiple of 32
 #pragma unroll
             for (int q0 = 0; q0 < XPASS; q0 += XG) {
                 if (q0 * RPS >= xrows) break;
                 f32x4 xv[XG];
 #pragma unroll
                 for (int q = 0; q < XG; ++q) {
-                    const int r = (q0 + q) * RPS + srow;
-                    const int gr = n0 - p.halo_lo + r;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (cok && r < xrows && gr >= 0 && gr < p.nrows && !(p.dbg & 1)) v = ev_bload4(rX, ((unsigned)gr * p.ldx + xcol) * 4u, 0);
+                    if ((q0 + q) * RPS < xrows && !(p.dbg & 1)) v = ev_bload4(rX, xoff[q0 + q], soff);
                     xv[q] = v;
                 }
 #pragma unroll
                 for (int q = 0; q < XG; ++q) {
                     const int r = (q0 + q) * RPS + srow;
                     f32x4 v = xv[q];
+                    if (ctail && c0 + sc4 >= p.Cin) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
                     if (p.pro_lrelu) {
                         v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
                         v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
@@ -662,6 +675,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
+// (A loader-wave build of this kernel — two extra waves per workgroup that only stage X tiles, so that the MFMA waves
+// never wait for HBM behind their in-order vmcnt — was built and measured 5-30 % SLOWER on every shape: a wave that
+// streams MFMAs back to back starves every dependent instruction chain of the other waves on its SIMD
+// (tools/valu_under_mfma.hip, profiles/r01_valu_under_mfma.log), so the loaders only ran in the MFMA waves' gaps.)
+
 // ---------------------------------------------------------------------------
 // resblock_pair_kernel: one (c1, c2) pair of HiFi-GAN ResBlock1 (hifigan/models.py:90-97) in ONE launch:
 //     x' = c2( lrelu( c1( lrelu(x) ) + b1 ) ) + b2 + x          c1: k taps, dilation d;  c2: k taps, dilation 1
@@ -714,7 +732,7 @@ __global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kerne
         if (dist >= pp.out_rows || n0 + dist >= p.nrows) return;
     }
 
-    const int MT32 = p.Mpad >> 5, KG8 = p.Kpad >> 3;
+    const int KG8 = p.Kpad >> 3;
     const unsigned wlane = (unsigned)lane * 16u;
     const __amdgpu_buffer_rsrc_t rX = ev_rsrc(p.X);
     f32x16 acc[TM][TN];
@@ -724,7 +742,7 @@ __global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kerne
     // (the accumulators start from the layer's bias when `binit` is given: C/D register 4g+e is channel 8g + 4*half + e)
     auto phase = [&](const float* Wf, const int2* tl, int nact, const float* binit, auto&& chunk_base) {
         const __amdgpu_buffer_rsrc_t rW = ev_rsrc(Wf);
-        auto a_off = [&](int tap, int kg8) -> unsigned { return (unsigned)(((tap * MT32 + wm) * KG8 + kg8) * 1024); };
+        auto a_off = [&](int tap_bytes, int kg8) -> unsigned { return (unsigned)tap_bytes + (unsigned)(wm * KG8 + kg8) * 1024u; };
         auto ldAp = [&](f32x4 (&dst)[TM], unsigned aoff) { dst[0] = ev_bload4(rW, wlane, aoff); };
         auto ldB = [&](f32x4 (&dst)[TN], const float* brow, int kg) {
 #pragma unroll
