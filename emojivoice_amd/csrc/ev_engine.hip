@@ -375,6 +375,11 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     // launches far below one round of workgroups are a latency chain per workgroup: use the build that prefetches the
     // next chunk's X tile through registers (measured 7-10 % on batch-1 decodes, nothing on full grids)
     if (cfg == 6 && (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64) <= 320) cfg = 8;
+    // deep grids (>= 6 rounds of 64x128 tiles, dense taps): larger tiles amortise the X staging and the weight-fragment stream over
+    // twice the MFMAs — measured on the HiFi-GAN layers (tools/shape_profile.py with EV_FORCE_CFG): 128x128 is 2-3 % faster
+    // for Cin <= 128 and for 3-tap layers, 64x192 for the 7 / 11-tap layers at Cin = 256
+    if (cfg == 1 && L.Cout % 128 == 0 && !L.sparse_taps && (long)(L.Cout / 64) * ((g.nrows + 127) / 128) >= 256L * 4 * 6)
+        cfg = (L.Cin > 128 && L.ntaps >= 7) ? 5 : 0;
     {   // debugging / test override: EV_FORCE_CFG=<0..3> forces one tile configuration for every conv launch
         static const char* env = getenv("EV_FORCE_CFG");
         if (env && *env) cfg = atoi(env);
