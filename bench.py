@@ -194,6 +194,23 @@ def main():
         path_roof = {"fp32_frac": round(per_gpu * ALG_FLOP_PER_AUDIO_S / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
                      "hbm_frac": round(per_gpu * ALG_BYTES_PER_AUDIO_S / (PEAK_HBM_GBS * 1e9), 4),
                      "note": "whole-path fractions from SURVEY §8(d) per-audio-second work; the fp32 MFMA roof binds"}
+        # PCIe-inclusive rate (never `value`): the same step plus the D2H copy of the waveform block into pinned host memory
+        pcie = None
+        try:
+            host_wav = torch.empty((B,) + tuple(wav.shape[1:]), dtype=torch.float32, pin_memory=True)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            host_wav.copy_(step_local(), non_blocking=True)
+            torch.cuda.synchronize()
+            dtp = time.perf_counter() - tp
+            td = time.perf_counter()
+            host_wav.copy_(wav[:B], non_blocking=True)
+            torch.cuda.synchronize()
+            pcie = {"audio_s_per_s_per_gpu": round(B * T * HOP / SR / dtp, 2), "ms_per_step": round(dtp * 1e3, 2),
+                    "d2h_ms": round((time.perf_counter() - td) * 1e3, 3), "d2h_MB": round(host_wav.numel() * 4 / 1e6, 1)}
+            del host_wav
+        except Exception as ex:  # pinned allocation can be refused on small hosts: the field stays null
+            log(f"[bench] pcie-inclusive probe skipped: {ex}")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             s = min(args.cpu_sample, B)
@@ -211,7 +228,7 @@ def main():
                        "global_batch": B * world, "frames": T, "ode_steps": n_ode, "parallelism": f"dp{world}",
                        "collective": "all_gather(waveforms)" if world > 1 else "none"},
             "per_gpu_audio_s_per_s": round(per_gpu, 2), "rtf": round(1.0 / per_gpu, 6), "x_realtime_per_gpu": round(per_gpu, 1),
-            "roofline": roofline, "path_roofline": path_roof, "cpu_baseline": cpu,
+            "roofline": roofline, "path_roofline": path_roof, "cpu_baseline": cpu, "pcie_inclusive": pcie,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
