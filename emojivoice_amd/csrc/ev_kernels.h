@@ -532,9 +532,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             ldAp(A0, a0); ldAp(A1, a0 + 1024u); ldAp(A2, a0 + 2048u);
         }
         for (int ch = 0; ch < nchunks; ++ch) {
-            __syncthreads();            // previous chunk's MFMAs are done with Xs
+            ev_lds_barrier();            // previous chunk's MFMAs are done with Xs
             x_store();
-            __syncthreads();
+            ev_lds_barrier();
             if (ch + 1 < nchunks) x_load(ch + 1);
             int tap = tv_first.x;
             const float* brow = bbase + tv_first.y * LDK;
@@ -587,7 +587,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         if (sub == 0) {
         __builtin_amdgcn_s_setprio(3);
         if (p.dbg & 2) ts0 = __builtin_amdgcn_s_memrealtime();
-        if (!(p.dbg & 8)) __syncthreads();  // previous chunk's MFMAs are done with Xs (dbg 8: timing-only ablation without barriers)
+        if (!(p.dbg & 8)) ev_lds_barrier();  // previous chunk's MFMAs are done with Xs (dbg 8: timing-only ablation without barriers)
         if (p.dbg & 2) { const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(); acc_b1 += t1 - ts0; }
         {
             // ---- stage the X tile of these KB k-chunks (with the optional prologue leaky-relu): all loads of a batch first.
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 }
             }
         }
-        if (!(p.dbg & 8)) __syncthreads();
+        if (!(p.dbg & 8)) ev_lds_barrier();
         __builtin_amdgcn_s_setprio(0);
         if (p.dbg & 2) acc_st += __builtin_amdgcn_s_memrealtime() - ts0;
         }
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kerne
     // ---------------- phase 1: c1 over lrelu(x), X tile rows [g0 - h1, g0 + NT + h1) staged per 32-channel chunk
     const int xrows = NT + 2 * pp.h1;
     phase(pp.W1, pp.taplist1, pp.ntaps1, pp.b1, [&](int ch) -> const float* {
-        __syncthreads();
+        ev_lds_barrier();
         const int c = ch * EV_BK + sc4;
         f32x4 xv[XPASS];
 #pragma unroll
@@ -827,12 +827,12 @@ __global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kerne
             v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
             if (r < xrows) *(f32x4*)(Xs + r * EV_LDK + sc4) = v;
         }
-        __syncthreads();
+        ev_lds_barrier();
         return Xs + (wn * (TN * 32) + li + pp.h1) * EV_LDK + 4 * lh;
     });
 
     // ---------------- y1 = lrelu(c1 + b1), zero outside the utterance, into LDS [chunk = wm][row + h2][channel]
-    __syncthreads();                                    // every wave is done reading Xs
+    ev_lds_barrier();                                    // every wave is done reading Xs
     {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kerne
             *(f32x4*)(Ys + (chn * YROWS + row) * EV_LDK + c4) = z;
         }
     }
-    __syncthreads();
+    ev_lds_barrier();
 
     // ---------------- phase 2: c2 over the LDS-resident y1 (tap i reads rows r + i)
     phase(p.W, p.taplist, p.ntaps, LEAN ? p.bias : nullptr, [&](int ch) -> const float* {
