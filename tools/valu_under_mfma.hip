@@ -7,7 +7,8 @@
 //   5 one ds_read + dependent use per 16 MFMAs (a real wait), 7 s_nop 7 after every MFMA.
 // Findings (profiles/r01_valu_under_mfma.log): a wave that streams MFMAs back to back keeps its 64.0 cycles/MFMA and
 // STARVES every dependent instruction chain of the other wave on its SIMD (no progress until the stream ends;
-// s_setprio does not help); independent v_fma streams and v_pk_fma chains co-issue at full speed.  The victim only
+// s_setprio does not help).  (Short independent streams can look unaffected here because they finish before the MFMA
+// waves have started; tools/hybrid_peak.hip is the chip-wide, long-running version of that case.)  The victim only
 // advances in the gaps where the MFMA wave issues something else, and every such gap costs the MFMA wave pipe time.
 //   hipcc --offload-arch=gfx950 -O3 tools/valu_under_mfma.hip -o tools/valu_under_mfma && tools/valu_under_mfma
 #include <hip/hip_runtime.h>
