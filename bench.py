@@ -95,8 +95,8 @@ def cpu_baseline(sd, voc_sd, mu, z0, spk, n_ode):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=516, help="mel frames per utterance (516 = 5.99 s)")
     ap.add_argument("--ode-steps", type=int, default=10)

@@ -1,0 +1,56 @@
+"""The kernel A/B switches (tile configuration, two-chunk staging, generic instead of lean epilogue, unfused resblock pairs)
+must not change results: every build accumulates in the same (chunk, tap, k-group) order, so the variants agree with the
+default path to fp32 rounding of the epilogue (bias added before vs after the K loop).  The switches are read once per
+process, hence one child process per variant."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys, torch
+sys.path.insert(0, %r)
+from emojivoice_amd import weights as W
+from emojivoice_amd.hifigan import AttrDict, Generator, v1
+from emojivoice_amd.matcha_tts import MatchaTTS
+dev = torch.device("cuda", 0)
+g = torch.Generator().manual_seed(7)
+B, T = 3, 44
+m = MatchaTTS(W.synthetic_matcha_state(), device=dev)
+voc = Generator(AttrDict(v1)).to(dev); voc.load_state_dict(W.synthetic_hifigan_state())
+mu = torch.randn(B, 80, T, generator=g).to(dev); z = (torch.randn(B, 80, T, generator=g) * 0.667).to(dev)
+lengths = torch.tensor([44, 31, 17], dtype=torch.int32).to(dev)
+spk = m._sd["spk_emb.weight"][torch.tensor([1, 5, 9], device=dev)]
+mel = m.engine.cfm_decode(mu, lengths, spk, z, 4, m.mel_std, m.mel_mean)
+wav = voc(mel)
+torch.save({"mel": mel.cpu(), "wav": wav.cpu()}, sys.argv[1])
+""" % REPO
+
+VARIANTS = [{"EV_KB": "2"}, {"EV_NO_LEAN": "1"}, {"EV_FUSE_PAIRS": "0"}, {"EV_FORCE_CFG": "0"}, {"EV_FORCE_CFG": "5"}, {"EV_FORCE_CFG": "6"},
+            {"EV_FORCE_CFG": "4"}]
+
+
+def _run(tmp_path, name, extra):
+    out = tmp_path / f"{name}.pt"
+    env = dict(os.environ)
+    env.update(extra)
+    r = subprocess.run([sys.executable, "-c", CHILD, str(out)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    import torch
+
+    return torch.load(out)
+
+
+def test_kernel_variants_agree(tmp_path):
+    ref = _run(tmp_path, "default", {})
+    assert float(ref["wav"].abs().max()) > 1e-3 and float(ref["mel"].abs().max()) > 1e-1
+    for i, extra in enumerate(VARIANTS):
+        got = _run(tmp_path, f"v{i}", extra)
+        dmel = float((got["mel"] - ref["mel"]).abs().max())
+        dwav = float((got["wav"] - ref["wav"]).abs().max())
+        assert dmel <= 2e-5 and dwav <= 2e-5, (extra, dmel, dwav)
