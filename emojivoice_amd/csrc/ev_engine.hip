@@ -90,6 +90,8 @@ struct ev_handle {
     bool fuse_pairs = true;     // EV_FUSE_PAIRS=0 disables resblock_pair_kernel (A/B runs)
     int fuse128 = 3;            // fuse C=128 pairs up to this kernel size (EV_FUSE128=0/3/7/11)
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    hipStream_t ws_stream = nullptr; bool ws_stream_valid = false;   // stream of the last call that used the workspace
+    float* temb_host[2] = {nullptr, nullptr}; size_t temb_cap[2] = {0, 0}; hipEvent_t temb_ev[2] = {nullptr, nullptr}; int temb_slot = 0;
     double prof_flops = 0; int64_t prof_launches = 0;
     struct ProfRec { int kind, Cin, Cout, ntaps, nrows, cfg, lean; double flops; };
     std::vector<ProfRec> prof_recs;   // one per timed launch (EV_PROFILE_DUMP=<file> writes the per-shape table)
@@ -621,6 +623,10 @@ int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
     // keep the other path's last shape so alternating cfm/hifigan calls do not thrash
     if (Tp <= 0) Tp = h->ws_Tp > 0 && h->ws_B == B ? h->ws_Tp : 0;
     if (Tv <= 0) Tv = h->ws_Tv > 0 && h->ws_B == B ? h->ws_Tv : 0;
+    // the workspace is shared by every call on this handle: a caller that moves to another stream must not overtake the
+    // previous call's kernels (one handle = one stream user at a time, include/emojivoice.h)
+    if (h->ws_stream_valid && h->ws_stream != h->stream) HIPCHK(h, hipStreamSynchronize(h->ws_stream));
+    h->ws_stream = h->stream; h->ws_stream_valid = true;
     const size_t need = plan_all(h, nullptr, B, Tp, Tv, nullptr, nullptr);
     bool rezero = (B != h->ws_B || Tp != h->ws_Tp || Tv != h->ws_Tv);
     if (need > h->ws_bytes) {
@@ -728,8 +734,22 @@ int run_time_mlp(ev_handle* h, EstBufs& b, const std::vector<float>& ts) {
             emb[(size_t)i * dim + half + k] = cosf(a);
         }
     }
-    HIPCHK(h, hipMemcpyAsync(b.temb_in, emb.data(), emb.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));  // emb is a stack-lifetime host buffer
+    {   // staged through a two-slot pinned ring owned by the handle: no host/stream synchronisation per call, so a caller
+        // that pipelines consecutive batches on two streams (emojivoice_amd/pipeline.py) keeps enqueueing ahead of the GPU
+        const size_t bytes = emb.size() * sizeof(float);
+        const int slot = (h->temb_slot ^= 1);
+        if (h->temb_cap[slot] < bytes) {
+            if (h->temb_host[slot]) { HIPCHK(h, hipEventSynchronize(h->temb_ev[slot])); HIPCHK(h, hipHostFree(h->temb_host[slot])); }
+            HIPCHK(h, hipHostMalloc((void**)&h->temb_host[slot], bytes, hipHostMallocDefault));
+            h->temb_cap[slot] = bytes;
+            if (!h->temb_ev[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->temb_ev[slot], hipEventDisableTiming));
+        } else {
+            HIPCHK(h, hipEventSynchronize(h->temb_ev[slot]));   // the copy issued two calls ago has read this slot
+        }
+        memcpy(h->temb_host[slot], emb.data(), bytes);
+        HIPCHK(h, hipMemcpyAsync(b.temb_in, h->temb_host[slot], bytes, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipEventRecord(h->temb_ev[slot], h->stream));
+    }
     Geom gt{nt, nt, 0, nt};
     Epi e1; e1.act = ACT_SILU;
     if (launch_conv(h, w.t1, b.temb_in, dim, b.temb_a, 1024, gt, e1)) return 1;
@@ -793,6 +813,7 @@ void ev_destroy(ev_handle* h) {
     for (void* p : h->owned) hipFree(p);
     if (h->ws) hipFree(h->ws);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    for (int i = 0; i < 2; ++i) { if (h->temb_ev[i]) hipEventDestroy(h->temb_ev[i]); if (h->temb_host[i]) hipHostFree(h->temb_host[i]); }
     delete h;
 }
 

@@ -240,3 +240,24 @@ def test_vocoder_batch_chunking_matches(vocoder):
     full = vocoder(mel)
     parts = torch.cat([vocoder(mel[:2]), vocoder(mel[2:])], dim=0)
     assert _linf(full, parts.cpu()) <= 1e-6
+
+
+def test_batch_pipeline_is_bit_identical(model, vocoder):
+    """Two-stream software pipeline over consecutive batches (emojivoice_amd/pipeline.py): same results as the two stages
+    called back to back, for every batch in flight."""
+    from emojivoice_amd.pipeline import BatchPipeline
+
+    g = torch.Generator().manual_seed(33)
+    B, Tp = 3, 36
+    spk = model._sd["spk_emb.weight"][torch.tensor([2, 4, 6]).cuda()]
+    lengths = torch.tensor([36, 20, 29], dtype=torch.int32).cuda()
+    batches = [(torch.randn(B, 80, Tp, generator=g).cuda(), (torch.randn(B, 80, Tp, generator=g) * 0.667).cuda()) for _ in range(4)]
+    ref = []
+    for mu, z in batches:
+        mel = model.engine.cfm_decode(mu, lengths, spk, z, 3, model.mel_std, model.mel_mean)
+        ref.append(vocoder(mel).cpu())
+    pipe = BatchPipeline(model, vocoder)
+    outs = [pipe.submit(mu, lengths, spk, z, 3) for mu, z in batches]
+    pipe.synchronize()
+    for r, o in zip(ref, outs):
+        assert torch.equal(r, o.cpu())
