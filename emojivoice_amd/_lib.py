@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libemojivoice_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 EXPORTS = [
-    "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder",
+    "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder", "ev_load_text_encoder", "ev_text_encoder",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention",
 ]
@@ -73,13 +73,14 @@ def load_library() -> C.CDLL:
     lib.ev_destroy.restype = None
     lib.ev_last_error.argtypes = [vp]
     lib.ev_last_error.restype = C.c_char_p
-    for f in (lib.ev_load_estimator, lib.ev_load_vocoder):
+    for f in (lib.ev_load_estimator, lib.ev_load_vocoder, lib.ev_load_text_encoder):
         f.argtypes = [vp, vp, C.POINTER(ev_tensor_index), u64]
     lib.ev_workspace_bytes.argtypes = [vp, i32, i32, i32]
     lib.ev_workspace_bytes.restype = u64
     lib.ev_cfm_decode.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp]
     lib.ev_estimator.argtypes = [vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]
     lib.ev_hifigan.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.ev_text_encoder.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.ev_profile_enable.argtypes = [vp, i32]
     lib.ev_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     lib.ev_op_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
@@ -154,6 +155,25 @@ class Engine:
 
     def load_vocoder(self, tensors: Dict[str, torch.Tensor]):
         self._load(self.lib.ev_load_vocoder, tensors, "ev_load_vocoder")
+
+    def load_text_encoder(self, tensors: Dict[str, torch.Tensor]):
+        self._load(self.lib.ev_load_text_encoder, tensors, "ev_load_text_encoder")
+
+    def text_encoder(self, ids, lengths, spk):
+        """(mu_x (B,80,Tx), logw (B,1,Tx)) of TextEncoder.forward (text_encoder.py:378-410), masked by the token lengths."""
+        assert ids.is_cuda and ids.dim() == 2
+        ids = ids.to(torch.int64).contiguous()
+        B, Tx = ids.shape
+        lengths = lengths.to(ids.device, torch.int32).contiguous()
+        spk_p = None
+        if spk is not None:
+            spk = self._f32(spk)
+            spk_p = spk.data_ptr()
+        mu = torch.empty((B, 80, Tx), dtype=torch.float32, device=ids.device)
+        logw = torch.empty((B, 1, Tx), dtype=torch.float32, device=ids.device)
+        self._check(self.lib.ev_text_encoder(self.h, ids.data_ptr(), lengths.data_ptr(), spk_p, B, Tx, mu.data_ptr(), logw.data_ptr(), _stream_ptr()),
+                    "ev_text_encoder")
+        return mu, logw
 
     # ---- hot calls -----------------------------------------------------------
     @staticmethod

@@ -73,6 +73,17 @@ struct VocoderW {
     float* post_w = nullptr; float post_b = 0.f; int post_k = 0;   // conv_post as [K][C] for conv_post_kernel
 };
 
+// Text encoder + duration predictor (text_encoder.py:328-410); hidden width C = n_channels + spk_emb_dim
+struct EncLayerW { ConvLayer qkv, out, ff1, ff2; float *g1, *b1, *g2, *b2; };
+struct TextEncW {
+    bool loaded = false;
+    int nvocab = 0, nch = 0, C = 0, heads = 0, nlayers = 0, ffc = 0;
+    float* emb = nullptr; float* theta = nullptr;
+    ConvLayer pre[3], pre_proj; float *pre_g[3], *pre_b[3];
+    std::vector<EncLayerW> layers;
+    ConvLayer proj_m, dp1, dp2, dp_proj; float *dp_g1, *dp_b1, *dp_g2, *dp_b2;
+};
+
 }  // namespace
 
 struct ev_handle {
@@ -82,6 +93,8 @@ struct ev_handle {
     std::vector<void*> owned;   // device allocations of the weights
     EstimatorW est;
     VocoderW voc;
+    TextEncW enc;
+    char* enc_ws = nullptr; size_t enc_ws_bytes = 0;   // the text encoder's own (small) workspace
     // workspace
     char* ws = nullptr; size_t ws_bytes = 0; size_t ws_used = 0;
     int ws_B = -1, ws_Tp = -1, ws_Tv = -1;
@@ -778,6 +791,101 @@ int prep_inputs(ev_handle* h, EstBufs& b, const float* d_x, const float* d_mu, c
     return 0;
 }
 
+int launch_cln(ev_handle* h, const float* X, int ldx, const float* R, int ldr, const float* g, const float* b, const float* rowmask, float* Y, int ldy,
+               const Geom& geo, int C, int relu) {
+    CLNParams p;
+    p.X = X; p.ldx = ldx; p.R = R; p.ldr = ldr; p.gamma = g; p.beta = b; p.rowmask = rowmask; p.Y = Y; p.ldy = ldy;
+    p.nrows = geo.nrows; p.S = geo.S; p.P = geo.P; p.T = geo.T; p.relu = relu; p.eps = 1e-4f;
+    if (C == 192) hipLaunchKernelGGL(chan_layernorm_kernel<3>, dim3((geo.nrows + 3) / 4), dim3(256), 0, h->stream, p);
+    else if (C == 256) hipLaunchKernelGGL(chan_layernorm_kernel<4>, dim3((geo.nrows + 3) / 4), dim3(256), 0, h->stream, p);
+    else return fail(h, "channel LayerNorm width %d not supported (192 / 256)", C);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// TextEncoder.forward (text_encoder.py:378-410) + DurationPredictor (:70-94).  Every activation is kept multiplied by the
+// frame mask: convolutions and attention only ever see masked inputs in the reference too, and the per-frame ops
+// (LayerNorm, 1x1 convs, residual adds) cannot carry a padded frame's value into a valid one, so valid frames are unchanged.
+int run_text_encoder(ev_handle* h, const int64_t* d_ids, const int32_t* d_len, const float* d_spk, int B, int Tx, float* d_mu, float* d_logw) {
+    const TextEncW& w = h->enc;
+    const int P = 2, S = Tx + 2 * P;
+    const Geom g{B * S, S, P, Tx};
+    const size_t n = (size_t)g.nrows;
+    const int C = w.C, nc = w.nch;
+    // workspace (floats): rm | E | Xm | A | H | H1 | Y | D | D2 | QKV | ATT | FF | MU | LW
+    const size_t need = (n * (1 + 3 * nc + 3 * C + 2 * w.dp1.Cout + 3 * C + C + w.ffc + 80 + 4) + 1024) * sizeof(float);
+    if (need > h->enc_ws_bytes) {
+        HIPCHK(h, hipDeviceSynchronize());
+        if (h->enc_ws) HIPCHK(h, hipFree(h->enc_ws));
+        h->enc_ws = nullptr; h->enc_ws_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&h->enc_ws, need));
+        h->enc_ws_bytes = need;
+    }
+    HIPCHK(h, hipMemsetAsync(h->enc_ws, 0, need, h->stream));     // pad rows are the convolutions' zero padding
+    Bump bp; bp.base = h->enc_ws; bp.off = 0;
+    float* rm = bp.take(n); float* E = bp.take(n * nc); float* Xm = bp.take(n * nc); float* A = bp.take(n * nc);
+    float* H = bp.take(n * C); float* H1 = bp.take(n * C); float* Y = bp.take(n * C);
+    float* D = bp.take(n * w.dp1.Cout); float* D2 = bp.take(n * w.dp1.Cout);
+    float* QKV = bp.take(n * 3 * C); float* ATT = bp.take(n * C); float* FF = bp.take(n * w.ffc);
+    float* MU = bp.take(n * 80); float* LW = bp.take(n * 4);
+    hipStream_t st = h->stream;
+    hipLaunchKernelGGL(rowmask_kernel, dim3((g.nrows + 255) / 256), dim3(256), 0, st, rm, d_len, g.nrows, g.S, g.P, g.T, 1);
+    {
+        const long tot = (long)B * Tx * (nc / 4);
+        hipLaunchKernelGGL(enc_embed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_ids, d_len, (const float*)w.emb, w.nvocab, sqrtf((float)nc),
+                           E, Xm, nc, B, Tx, S, P);
+    }
+    HIPCHK(h, hipGetLastError());
+    // prenet ConvReluNorm (:36-67): 3 x [conv k5 -> LayerNorm -> ReLU], then x_org + proj(x), masked
+    for (int i = 0; i < 3; ++i) {
+        { Epi e; if (launch_conv(h, w.pre[i], Xm, nc, A, nc, g, e)) return 1; }
+        if (launch_cln(h, A, nc, nullptr, 0, w.pre_g[i], w.pre_b[i], rm, Xm, nc, g, nc, 1)) return 1;
+    }
+    { Epi e; e.R = E; e.ldr = nc; e.mask2 = 1; e.rowmask = rm; if (launch_conv(h, w.pre_proj, Xm, nc, H, C, g, e)) return 1; }
+    if (C > nc) {
+        const long tot = (long)g.nrows * (C - nc);
+        hipLaunchKernelGGL(bcast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_spk, H, C, nc, C - nc, g.nrows, g.S, g.P, g.T, (const float*)rm);
+        HIPCHK(h, hipGetLastError());
+    }
+    // Encoder (:276-325)
+    const int kc = C / w.heads;
+    for (int l = 0; l < w.nlayers; ++l) {
+        const EncLayerW& L = w.layers[l];
+        { Epi e; if (launch_conv(h, L.qkv, H, C, QKV, 3 * C, g, e)) return 1; }
+        {
+            const long tot = (long)g.nrows * 2 * w.heads * (kc / 4);
+            hipLaunchKernelGGL(enc_rope_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, QKV, 3 * C, (const float*)w.theta, w.heads, kc, kc / 2,
+                               g.nrows, g.S, g.P, g.T);
+            hipLaunchKernelGGL(enc_attention_kernel, dim3((Tx + 3) / 4, w.heads, B), dim3(256), 0, st, (const float*)QKV, 3 * C, d_len, ATT, C, w.heads, kc, B, Tx, S, P,
+                               sqrtf((float)kc));
+            HIPCHK(h, hipGetLastError());
+        }
+        { Epi e; e.R = H; e.ldr = C; if (launch_conv(h, L.out, ATT, C, Y, C, g, e)) return 1; }                  // x + attn(x)
+        if (launch_cln(h, Y, C, nullptr, 0, L.g1, L.b1, rm, H1, C, g, C, 0)) return 1;
+        { Epi e; e.act = ACT_LRELU; e.act_slope = 0.f; e.mask1 = 1; e.rowmask = rm; if (launch_conv(h, L.ff1, H1, C, FF, w.ffc, g, e)) return 1; }   // relu
+        { Epi e; e.mask1 = 1; e.rowmask = rm; e.R = H1; e.ldr = C; if (launch_conv(h, L.ff2, FF, w.ffc, Y, C, g, e)) return 1; }                    // x + ffn(x)*m
+        if (launch_cln(h, Y, C, nullptr, 0, L.g2, L.b2, rm, H, C, g, C, 0)) return 1;
+    }
+    { Epi e; e.mask1 = 1; e.rowmask = rm; if (launch_conv(h, w.proj_m, H, C, MU, 80, g, e)) return 1; }
+    {
+        dim3 grid((Tx + 31) / 32, (80 + 31) / 32, B);
+        hipLaunchKernelGGL(fm_to_cm_kernel, grid, dim3(256), 0, st, (const float*)MU, 80, 0, d_mu, 80, Tx, S, P, 1.0f, 0.0f);
+    }
+    // DurationPredictor (:70-94): conv k3 -> ReLU -> LayerNorm (x2) at filter_channels_dp, 1x1 projection, masked
+    const int fd = w.dp1.Cout;
+    { Epi e; e.act = ACT_LRELU; e.act_slope = 0.f; if (launch_conv(h, w.dp1, H, C, D, fd, g, e)) return 1; }
+    if (launch_cln(h, D, fd, nullptr, 0, w.dp_g1, w.dp_b1, rm, D2, fd, g, fd, 0)) return 1;
+    { Epi e; e.act = ACT_LRELU; e.act_slope = 0.f; if (launch_conv(h, w.dp2, D2, fd, D, fd, g, e)) return 1; }
+    if (launch_cln(h, D, fd, nullptr, 0, w.dp_g2, w.dp_b2, rm, D2, fd, g, fd, 0)) return 1;
+    { Epi e; e.mask1 = 1; e.rowmask = rm; if (launch_conv(h, w.dp_proj, D2, fd, LW, 1, g, e)) return 1; }
+    {
+        const size_t total = (size_t)B * Tx;
+        hipLaunchKernelGGL(strip_pad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const float*)LW, d_logw, Tx, S, P, total);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -813,6 +921,7 @@ void ev_destroy(ev_handle* h) {
     for (void* p : h->owned) hipFree(p);
     if (h->ws) hipFree(h->ws);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
+    if (h->enc_ws) hipFree(h->enc_ws);
     for (int i = 0; i < 2; ++i) { if (h->temb_ev[i]) hipEventDestroy(h->temb_ev[i]); if (h->temb_host[i]) hipHostFree(h->temb_host[i]); }
     delete h;
 }
@@ -957,6 +1066,99 @@ int ev_load_vocoder(ev_handle* h, const float* blob, const ev_tensor_index* inde
 }
 #undef T_
 #undef REQ
+
+#define T_(k) find(h, m, k)
+#define REQ(x) do { if (x) return 1; } while (0)
+int ev_load_text_encoder(ev_handle* h, const float* blob, const ev_tensor_index* index, size_t n) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    TensorMap m;
+    if (build_map(h, blob, index, n, m)) return 1;
+    TextEncW& w = h->enc;
+    w.loaded = false;
+    w.layers.clear();
+    const HostTensor* emb = T_("emb.weight");
+    const HostTensor* th = T_("rope_theta");
+    if (!emb || !th) return 1;
+    w.nvocab = (int)emb->shape[0]; w.nch = (int)emb->shape[1];
+    REQ(upload_vec(h, m, "emb.weight", &w.emb));
+    REQ(upload_vec(h, m, "rope_theta", &w.theta));
+    for (int i = 0; i < 3; ++i) {
+        const std::string c = "prenet.conv_layers." + std::to_string(i), nn = "prenet.norm_layers." + std::to_string(i);
+        const HostTensor *cw = T_(c + ".weight"), *cb = T_(c + ".bias");
+        if (!cw || !cb) return 1;
+        REQ(pack_conv(h, w.pre[i], *cw, cb, 1));
+        REQ(upload_vec(h, m, nn + ".gamma", &w.pre_g[i]));
+        REQ(upload_vec(h, m, nn + ".beta", &w.pre_b[i]));
+    }
+    {
+        const HostTensor *pw = T_("prenet.proj.weight"), *pb = T_("prenet.proj.bias");
+        if (!pw || !pb) return 1;
+        REQ(pack_conv(h, w.pre_proj, *pw, pb, 1));
+    }
+    int nl = 0;
+    while (m.count("encoder.attn_layers." + std::to_string(nl) + ".conv_q.weight")) ++nl;
+    if (nl == 0) return fail(h, "text encoder: no encoder.attn_layers.* tensors");
+    w.nlayers = nl;
+    w.layers.resize(nl);
+    for (int l = 0; l < nl; ++l) {
+        const std::string a = "encoder.attn_layers." + std::to_string(l), f = "encoder.ffn_layers." + std::to_string(l);
+        const HostTensor *q = T_(a + ".conv_q.weight"), *k = T_(a + ".conv_k.weight"), *v = T_(a + ".conv_v.weight");
+        const HostTensor *qb = T_(a + ".conv_q.bias"), *kb = T_(a + ".conv_k.bias"), *vb = T_(a + ".conv_v.bias");
+        const HostTensor *ow = T_(a + ".conv_o.weight"), *ob = T_(a + ".conv_o.bias");
+        const HostTensor *f1w = T_(f + ".conv_1.weight"), *f1b = T_(f + ".conv_1.bias"), *f2w = T_(f + ".conv_2.weight"), *f2b = T_(f + ".conv_2.bias");
+        if (!q || !k || !v || !qb || !kb || !vb || !ow || !ob || !f1w || !f1b || !f2w || !f2b) return 1;
+        EncLayerW& L = w.layers[l];
+        REQ(pack_linear_stack(h, L.qkv, {q, k, v}, {qb, kb, vb}));
+        REQ(pack_linear_stack(h, L.out, {ow}, {ob}));
+        REQ(pack_conv(h, L.ff1, *f1w, f1b, 1));
+        REQ(pack_conv(h, L.ff2, *f2w, f2b, 1));
+        REQ(upload_vec(h, m, "encoder.norm_layers_1." + std::to_string(l) + ".gamma", &L.g1));
+        REQ(upload_vec(h, m, "encoder.norm_layers_1." + std::to_string(l) + ".beta", &L.b1));
+        REQ(upload_vec(h, m, "encoder.norm_layers_2." + std::to_string(l) + ".gamma", &L.g2));
+        REQ(upload_vec(h, m, "encoder.norm_layers_2." + std::to_string(l) + ".beta", &L.b2));
+    }
+    w.C = w.layers[0].out.Cout;
+    w.ffc = w.layers[0].ff1.Cout;
+    w.heads = 2;                                           // TextEncoder's n_heads (configs/model/encoder/default.yaml)
+    {
+        const int kc = w.C / w.heads;                      // 128 (multi-speaker) or 96 (single-speaker); rotary on int(kc * 0.5) features
+        if (w.C % w.heads || kc > 128 || (kc & 3) || (int)th->numel() != kc / 4)
+            return fail(h, "text encoder: head width %d with a rope table of %d entries is not supported", kc, (int)th->numel());
+    }
+    if (w.C != w.nch + h->dims.spk_emb_dim && w.C != w.nch) return fail(h, "text encoder width %d != n_channels %d (+ spk_emb_dim)", w.C, w.nch);
+    {
+        const HostTensor *mw = T_("proj_m.weight"), *mb = T_("proj_m.bias");
+        const HostTensor *d1w = T_("proj_w.conv_1.weight"), *d1b = T_("proj_w.conv_1.bias"), *d2w = T_("proj_w.conv_2.weight"), *d2b = T_("proj_w.conv_2.bias");
+        const HostTensor *dpw = T_("proj_w.proj.weight"), *dpb = T_("proj_w.proj.bias");
+        if (!mw || !mb || !d1w || !d1b || !d2w || !d2b || !dpw || !dpb) return 1;
+        REQ(pack_conv(h, w.proj_m, *mw, mb, 1));
+        REQ(pack_conv(h, w.dp1, *d1w, d1b, 1));
+        REQ(pack_conv(h, w.dp2, *d2w, d2b, 1));
+        REQ(pack_conv(h, w.dp_proj, *dpw, dpb, 1));
+        REQ(upload_vec(h, m, "proj_w.norm_1.gamma", &w.dp_g1));
+        REQ(upload_vec(h, m, "proj_w.norm_1.beta", &w.dp_b1));
+        REQ(upload_vec(h, m, "proj_w.norm_2.gamma", &w.dp_g2));
+        REQ(upload_vec(h, m, "proj_w.norm_2.beta", &w.dp_b2));
+    }
+    if (w.proj_m.Cout != 80) return fail(h, "proj_m width %d != 80", w.proj_m.Cout);
+    w.loaded = true;
+    return 0;
+}
+
+#undef T_
+#undef REQ
+
+int ev_text_encoder(ev_handle* h, const int64_t* d_ids, const int32_t* d_lengths, const float* d_spk, int B, int Tx, float* d_mu, float* d_logw, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->enc.loaded) return fail(h, "text encoder weights not loaded");
+    if (B <= 0 || Tx <= 0 || !d_ids || !d_lengths || !d_mu || !d_logw) return fail(h, "bad arguments B=%d Tx=%d", B, Tx);
+    if (h->enc.C > h->enc.nch && !d_spk) return fail(h, "speaker embedding required by a multi-speaker text encoder");
+    if ((double)B * (Tx + 4) * 3 * h->enc.C * 4.0 >= 4294967296.0) return fail(h, "text batch exceeds the 4 GiB buffer-addressing limit: split the batch");
+    h->stream = (hipStream_t)stream;
+    return run_text_encoder(h, d_ids, d_lengths, d_spk, B, Tx, d_mu, d_logw);
+}
 
 size_t ev_workspace_bytes(ev_handle* h, int B, int Tp_cfm, int T_voc) {
     if (!h || B <= 0) return 0;

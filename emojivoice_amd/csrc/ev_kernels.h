@@ -1216,6 +1216,119 @@ __global__ void bcast_rows_kernel(const float* v, float* dst, int ld, int c0, in
     dst[(size_t)n * ld + c0 + c] = v[b * C + c] * (rowmask ? rowmask[n] : 1.f);
 }
 
+// ---------------------------------------------------------------------------
+// Text encoder (text_encoder.py) support kernels.  The encoder is <1 % of the path's FLOPs (north_star keeps it a
+// once-per-utterance host stage); these kernels exist so that a streaming caller does not pay ~60 framework launches for
+// it.  All of its convolutions run on conv_gemm_kernel; what is left is elementwise / per-frame work.
+// ---------------------------------------------------------------------------
+// token embedding * sqrt(C) (text_encoder.py:395) into frame-major rows: E = emb[id]*s (unmasked), Xm = E * mask
+__global__ void enc_embed_kernel(const int64_t* ids, const int32_t* lengths, const float* emb, int nvocab, float scale, float* E, float* Xm,
+                                 int C, int B, int Tx, int S, int P) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4n = C / 4;
+    const int row = idx / c4n, c4 = (idx % c4n) * 4;
+    if (row >= B * Tx) return;
+    const int b = row / Tx, t = row % Tx;
+    long id = ids[row];
+    id = id < 0 ? 0 : (id >= nvocab ? nvocab - 1 : id);
+    f32x4 v = *(const f32x4*)(emb + (size_t)id * C + c4);
+    v *= scale;
+    const size_t n = (size_t)b * S + P + t;
+    *(f32x4*)(E + n * C + c4) = v;
+    if (t >= lengths[b]) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+    *(f32x4*)(Xm + n * C + c4) = v;
+}
+
+// channel-wise LayerNorm of text_encoder.py:15-33 (mean / biased variance over the channels of one frame, eps inside the
+// rsqrt), optionally on x + R, optionally followed by ReLU, always multiplied by the frame mask (see ev_engine.hip: the
+// encoder keeps every activation masked, which valid frames cannot observe).  One wavefront per frame, C = 64 * NPL.
+struct CLNParams { const float* X; int ldx; const float* R; int ldr; const float* gamma; const float* beta; const float* rowmask;
+                   float* Y; int ldy; int nrows, S, P, T; int relu; float eps; };
+template <int NPL>
+__global__ __launch_bounds__(256) void chan_layernorm_kernel(const CLNParams p) {
+    constexpr int C = 64 * NPL;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.nrows) return;
+    const int t = (n % p.S) - p.P;
+    if (t < 0 || t >= p.T) return;
+    float v[NPL], s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        v[i] = p.X[(size_t)n * p.ldx + lane + 64 * i];
+        if (p.R) v[i] += p.R[(size_t)n * p.ldr + lane + 64 * i];
+        s += v[i];
+    }
+    const float mean = wave_sum(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) { v[i] -= mean; q += v[i] * v[i]; }
+    const float rstd = rsqrtf(wave_sum(q) * (1.0f / C) + p.eps);
+    const float m = p.rowmask ? p.rowmask[n] : 1.f;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        float o = v[i] * rstd * p.gamma[lane + 64 * i] + p.beta[lane + 64 * i];
+        if (p.relu) o = fmaxf(o, 0.f);
+        p.Y[(size_t)n * p.ldy + lane + 64 * i] = o * m;
+    }
+}
+
+// rotary embedding (text_encoder.py:97-172) on the first D features of every head of the q and k blocks of a
+// [q | k | v] row, in place: pairs (j, j + D/2), angle = t * theta[j]  (theta = the reference's table, computed by the loader)
+__global__ void enc_rope_kernel(float* QKV, int ld, const float* theta, int heads, int kc, int D, int nrows, int S, int P, int T) {
+    const int half = D / 2;
+    const int per_row = 2 * heads * half;          // (q|k) x heads x pairs
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = idx / per_row, r = idx % per_row;
+    if (n >= nrows) return;
+    const int t = (n % S) - P;
+    if (t < 0 || t >= T) return;
+    const int blk = r / (heads * half), hh = (r / half) % heads, j = r % half;
+    float* x = QKV + (size_t)n * ld + blk * heads * kc + hh * kc;
+    const float ang = (float)t * theta[j];
+    const float c = cosf(ang), sn = sinf(ang);
+    const float a = x[j], b = x[j + half];
+    x[j] = a * c + (-b) * sn;
+    x[j + half] = b * c + a * sn;
+}
+
+// MultiHeadAttention core of text_encoder.py:216-246 for one query frame per wavefront (kc <= 128 features per head:
+// two per lane): scores = q.k / sqrt(kc), keys beyond the utterance length are masked_fill(-1e4) in the reference, i.e.
+// they contribute exp(-1e4 - max) = 0 exactly to a valid query — they are skipped here; queries beyond the length give 0
+// (their output is masked by every consumer).  Online softmax over the keys.
+__global__ __launch_bounds__(256) void enc_attention_kernel(const float* QKV, int ld, const int32_t* lengths, float* O, int ldo,
+                                                            int heads, int kc, int B, int Tx, int S, int P, float score_div) {
+    const int lane = threadIdx.x & 63;
+    const int tq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int hh = blockIdx.y, b = blockIdx.z;
+    if (tq >= Tx) return;
+    const int len = lengths[b] < Tx ? lengths[b] : Tx;
+    const size_t row0 = (size_t)b * S + P;
+    const bool act = 2 * lane < kc;
+    const int dq = hh * kc + (act ? 2 * lane : 0);
+    float2 o = make_float2(0.f, 0.f);
+    if (tq < len) {
+        float2 q = *(const float2*)(QKV + (row0 + tq) * ld + dq);
+        if (!act) q = make_float2(0.f, 0.f);
+        const float* Kb = QKV + row0 * ld + heads * kc + dq;
+        const float* Vb = QKV + row0 * ld + 2 * heads * kc + dq;
+        float m = -INFINITY, l = 0.f;
+        for (int j = 0; j < len; ++j) {
+            const float2 k = *(const float2*)(Kb + (size_t)j * ld);
+            const float2 v = *(const float2*)(Vb + (size_t)j * ld);
+            const float sc = wave_sum(q.x * k.x + q.y * k.y) / score_div;
+            const float mn = fmaxf(m, sc);
+            const float corr = expf(m - mn), pj = expf(sc - mn);
+            l = l * corr + pj;
+            o.x = o.x * corr + pj * v.x;
+            o.y = o.y * corr + pj * v.y;
+            m = mn;
+        }
+        o.x /= l; o.y /= l;
+    }
+    if (act) *(float2*)(O + (row0 + tq) * ldo + dq) = o;
+}
+
 // sinusoidal time embedding (decoder.py:14-29) for a list of times: emb[i][0:half] = sin, [half:] = cos
 __global__ void time_sinusoid_kernel(const float* tvals, float* emb, int nt, int dim, float scale) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;

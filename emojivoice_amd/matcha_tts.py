@@ -45,6 +45,20 @@ def estimator_tensors(sd: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Te
     return out
 
 
+def text_encoder_tensors(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Tensors handed to ``ev_load_text_encoder``: ``encoder.*`` without the prefix, plus the rotary frequency table built
+    with the reference's own expression (text_encoder.py:115-117; d = int(k_channels * 0.5), :196-199)."""
+    out: Dict[str, torch.Tensor] = {}
+    for k, v in sd.items():
+        if k.startswith("encoder."):
+            out[k[len("encoder."):]] = v.detach().float()
+    n_heads = 2
+    kc = out["encoder.attn_layers.0.conv_q.weight"].shape[0] // n_heads
+    d = int(kc * 0.5)
+    out["rope_theta"] = 1.0 / (10000.0 ** (torch.arange(0, d, 2).float() / d))
+    return out
+
+
 class MatchaTTS:
     def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", n_heads_encoder: int = 2, n_layers_encoder: int = 6):
         sd = {k: v.detach().float() for k, v in state_dict.items()}
@@ -56,6 +70,7 @@ class MatchaTTS:
         self.mel_std = float(sd.get("mel_std", torch.tensor(1.0)))
         self._cpu_sd = sd
         self._enc_cfg = (n_heads_encoder, n_layers_encoder)
+        self.encoder_stage = "device"   # "device": ev_text_encoder (HIP, through the C ABI); "host": the plain-torch TextEncoder
         self.rng = "cpu"   # "cpu": z drawn exactly as the reference CPU run draws it (seed parity); "device": torch.cuda RNG
         self.engine: Optional[Engine] = None
         self.device = torch.device("cpu")
@@ -77,7 +92,17 @@ class MatchaTTS:
             self.engine.close()
         self.engine = Engine(idx, spk_emb_dim=self.spk_emb_dim)
         self.engine.load_estimator(estimator_tensors(self._cpu_sd))
+        self.engine.load_text_encoder(text_encoder_tensors(self._cpu_sd))
         return self
+
+    def encode(self, x, x_lengths, spk):
+        """TextEncoder.forward (text_encoder.py:378-410): (mu_x, logw, x_mask).  ``encoder_stage = "host"`` runs the plain
+        torch restatement instead (north_star's "text encoder run once on host")."""
+        if self.encoder_stage == "host":
+            return self.encoder(x, x_lengths, spk)
+        mu_x, logw = self.engine.text_encoder(x, x_lengths, spk)
+        x_mask = sequence_mask(x_lengths, x.shape[1]).unsqueeze(1).to(mu_x.dtype)
+        return mu_x, logw, x_mask
 
     def state_dict(self):
         return dict(self._cpu_sd)
@@ -106,7 +131,7 @@ class MatchaTTS:
             spk = F.embedding(spks.to(dev).long(), self._sd["spk_emb.weight"])   # AttributeError on None, like the reference
         else:
             spk = None
-        mu_x, logw, x_mask = self.encoder(x, x_lengths, spk)
+        mu_x, logw, x_mask = self.encode(x, x_lengths, spk)
         w = torch.exp(logw) * x_mask
         w_ceil = torch.ceil(w) * length_scale
         y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()

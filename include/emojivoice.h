@@ -11,7 +11,11 @@
  *                        diffusers Attention, SnakeBeta    transformer.py:17-80)
  *   ev_hifigan      <-  Generator.forward                  hifigan/models.py:181-197
  *                       (ResBlock1.forward                 hifigan/models.py:90-97)
+ *   ev_text_encoder <-  TextEncoder.forward                models/components/text_encoder.py:378-410
+ *                       (ConvReluNorm :36-67, Encoder :276-325, MultiHeadAttention + RoPE :97-246, FFN :255-273,
+ *                        DurationPredictor :70-94, channel LayerNorm :15-33) — the caller of the hot path
  *   ev_load_estimator <- MatchaTTS.load_from_checkpoint -> state_dict["decoder.estimator.*"]   cli.py:110-118
+ *   ev_load_text_encoder <- same checkpoint, state_dict["encoder.*"] + the derived "rope_theta" table
  *   ev_load_vocoder   <- Generator.load_state_dict(ckpt["generator"]) + remove_weight_norm()   cli.py:84-90
  *
  * Conventions
@@ -68,6 +72,9 @@ const char *ev_last_error(ev_handle *h);
 /* Weights: host blob + index; copied and re-laid-out into library-owned device memory. */
 int ev_load_estimator(ev_handle *h, const float *blob, const ev_tensor_index *index, size_t n);
 int ev_load_vocoder(ev_handle *h, const float *blob, const ev_tensor_index *index, size_t n);
+/* Text-encoder keys: state_dict["encoder.<key>"] (matcha_tts.py:52-60) plus "rope_theta" =
+ * 1 / (10000 ** (arange(0, d, 2) / d)), d = 64  (text_encoder.py:115-117), computed by the loader with the reference's ops. */
+int ev_load_text_encoder(ev_handle *h, const float *blob, const ev_tensor_index *index, size_t n);
 
 /* Bytes of device workspace the two hot calls need at a given shape (0 on bad args). */
 size_t ev_workspace_bytes(ev_handle *h, int B, int Tp_cfm, int T_voc);
@@ -86,6 +93,15 @@ int ev_cfm_decode(ev_handle *h, const float *d_mu, const int32_t *d_lengths, con
 /* One estimator evaluation v = Decoder(x, mask, mu, t, spk)  (decoder.py:363-443). */
 int ev_estimator(ev_handle *h, const float *d_x, const float *d_mu, const int32_t *d_lengths, const float *d_spk,
                  float t, int B, int Tp, float *d_v, void *stream);
+
+/* Text encoder + duration predictor (the stage in front of ev_cfm_decode; matcha_tts.py:118-121):
+ *   d_ids     (B, Tx) int64  phoneme ids (torch.long, as the reference passes them)
+ *   d_lengths (B) int32      valid tokens per utterance (x_lengths; mask = t < length)
+ *   d_spk     (B, 64)        speaker/emoji embedding rows (NULL iff the model is single-speaker)
+ *   d_mu      (B, 80, Tx)    mu_x, masked          d_logw (B, Tx)  log-durations, masked
+ * Duration rounding, the monotonic alignment path and mu_y = attn^T mu_x stay with the caller (data-dependent sizes). */
+int ev_text_encoder(ev_handle *h, const int64_t *d_ids, const int32_t *d_lengths, const float *d_spk, int B, int Tx,
+                    float *d_mu, float *d_logw, void *stream);
 
 /* HiFi-GAN V1 generator: d_mel (B, 80, T) -> d_wav (B, 256*T), tanh output, no clamp/denoiser. */
 int ev_hifigan(ev_handle *h, const float *d_mel, int B, int T, float *d_wav, void *stream);

@@ -134,3 +134,21 @@ def test_hifigan_state_dict_roundtrip(voc_sd):
     bad.pop("conv_post.bias")
     with pytest.raises(RuntimeError):
         Generator(AttrDict(v1)).load_state_dict(bad)
+
+
+def test_text_encoder_tensor_export():
+    """Host loader of ev_load_text_encoder: ``encoder.*`` keys without the prefix + the rotary table of the reference's
+    expression (text_encoder.py:115-117) at d = int(k_channels * 0.5), for the multi- and single-speaker widths."""
+    import torch
+
+    from emojivoice_amd import weights as W
+    from emojivoice_amd.matcha_tts import text_encoder_tensors
+
+    for n_spks, kc in ((109, 128), (1, 96)):
+        sd = W.synthetic_matcha_state(178, n_spks)
+        t = text_encoder_tensors(sd)
+        assert "emb.weight" in t and "proj_w.proj.weight" in t and not any(k.startswith("encoder.emb") for k in t)
+        assert t["encoder.attn_layers.0.conv_q.weight"].shape[0] == 2 * kc
+        d = kc // 2
+        assert t["rope_theta"].shape == (d // 2,)
+        assert torch.equal(t["rope_theta"], 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d)))

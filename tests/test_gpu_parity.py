@@ -261,3 +261,25 @@ def test_batch_pipeline_is_bit_identical(model, vocoder):
     pipe.synchronize()
     for r, o in zip(ref, outs):
         assert torch.equal(r, o.cpu())
+
+
+def test_device_text_encoder_vs_golden_and_host(golden, model, matcha_sd):
+    """ev_text_encoder (HIP kernels through the C ABI) vs the reference-generated golden text-encoder outputs, vs the CPU
+    oracle on a ragged batch, and vs the plain-torch host stage."""
+    ids = T_(golden["g3_ids"]).long()
+    lens = T_(golden["g3_x_lengths"])
+    spk = model._sd["spk_emb.weight"][T_(golden["g3_spks"]).long().cuda()]
+    mu, logw = model.engine.text_encoder(ids.cuda(), lens.cuda(), spk)
+    assert _linf(mu, golden["g3_mu_x"]) <= 1e-4
+    assert _linf(logw, golden["g3_logw"]) <= 1e-4
+    # ragged batch incl. a length-1 utterance, vs the oracle
+    g = torch.Generator().manual_seed(5)
+    ids2 = torch.randint(1, 178, (4, 37), generator=g)
+    lens2 = torch.tensor([37, 1, 20, 9])
+    sid = torch.tensor([0, 3, 7, 10])
+    spk2 = model._sd["spk_emb.weight"][sid.cuda()]
+    mu2, logw2 = model.engine.text_encoder(ids2.cuda(), lens2.cuda(), spk2)
+    rmu, rlogw, _ = O.text_encoder(matcha_sd, ids2, lens2, torch.nn.functional.embedding(sid, matcha_sd["spk_emb.weight"]))
+    assert _linf(mu2, rmu) <= 1e-4 and _linf(logw2, rlogw) <= 1e-4
+    hmu, hlogw, _ = model.encoder(ids2.cuda(), lens2.cuda(), spk2)
+    assert _linf(mu2, hmu.cpu()) <= 1e-4 and _linf(logw2, hlogw.cpu()) <= 1e-4

@@ -73,7 +73,7 @@ if "5" in which:
         t0 = time.perf_counter()
         x = ids_h.to(dev)
         spk = model._sd["spk_emb.weight"][spk_h.to(dev)]
-        model.encoder(x, torch.tensor([Lx], device=dev), spk)             # host stage (its durations are replaced by the target T)
+        model.encode(x, torch.tensor([Lx], device=dev), spk)              # text encoder + duration predictor (its durations are replaced by the target T)
         mu = mu_h.to(dev)
         lengths = torch.tensor([T], device=dev)
         dec, mel = model.decode(mu, lengths, 10, 0.667, spk)

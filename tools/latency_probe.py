@@ -16,8 +16,9 @@ def run(T, tag):
     dec = model.engine.cfm_decode(mu, L, spk, z, 10); torch.cuda.synchronize(); t1 = time.perf_counter()
     wav = voc(dec); torch.cuda.synchronize(); t2 = time.perf_counter()
     x = torch.randint(1,178,(1, T//4)).to(dev)
-    model.encoder(x, torch.tensor([T//4], device=dev), spk); torch.cuda.synchronize(); t3 = time.perf_counter()
+    model.encode(x, torch.tensor([T//4], device=dev), spk); torch.cuda.synchronize(); t3 = time.perf_counter()
+    model.encoder(x, torch.tensor([T//4], device=dev), spk); torch.cuda.synchronize(); t3b = time.perf_counter()
     zz = model.draw_noise(1, Tp); torch.cuda.synchronize(); t4 = time.perf_counter()
-    print(f"{tag} T={T}: cfm {1e3*(t1-t0):.1f} ms, hifigan {1e3*(t2-t1):.1f} ms, encoder {1e3*(t3-t2):.1f} ms, noise {1e3*(t4-t3):.1f} ms")
+    print(f"{tag} T={T}: cfm {1e3*(t1-t0):.1f} ms, hifigan {1e3*(t2-t1):.1f} ms, encoder device {1e3*(t3-t2):.1f} ms / host {1e3*(t3b-t3):.1f} ms, noise {1e3*(t4-t3b):.1f} ms")
 for T in (516, 516, 516, 300, 300, 700, 700, 516, 100, 860, 860):
     run(T, "run")
