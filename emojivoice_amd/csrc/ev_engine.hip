@@ -314,8 +314,9 @@ void launch_cfg2(const ConvParams& p, hipStream_t st);
 inline bool lean_acc(const ConvParams& p) { return p.accum || p.div3 || p.act2_lrelu; }
 inline bool lean_ok(const ConvParams& p) {
     if (lean_acc(p) && (!p.R || p.act != ACT_NONE)) return false;
-    return (p.act == ACT_NONE || p.act == ACT_LRELU || (p.act == ACT_SNAKE && (((size_t)p.act_a | (size_t)p.act_b) & 15) == 0)) && !p.mask1 && !p.mask2 && p.scale == 1.f &&
-           !p.Y2 && !p.rowmask && p.osplit_log2 >= 31 && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (!p.R || (p.ldr & 3) == 0) &&
+    return (p.act == ACT_NONE || p.act == ACT_LRELU || (p.act == ACT_SNAKE && (((size_t)p.act_a | (size_t)p.act_b) & 15) == 0)) &&
+           ((!p.mask1 && !p.mask2) || (p.rowmask && p.mmul == 1 && !(p.mask2 && lean_acc(p)))) && p.scale == 1.f &&
+           !p.Y2 && p.osplit_log2 >= 31 && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (!p.R || (p.ldr & 3) == 0) &&
            (!p.bias || ((size_t)p.bias & 15) == 0) && !(p.dbg & 4);
 }
 static int g_kb = 1;   // k-chunks per stage for the launch being issued (see conv_gemm_kernel: KB)
@@ -341,6 +342,27 @@ void launch_cfg2(const ConvParams& p, hipStream_t st) {
     if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; }
     if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
+}
+
+// small-launch build (conv_gemm_sk_kernel): 64 x 64 tiles, 16 waves, K split four ways inside the workgroup
+template <bool FULL, int LEAN>
+void launch_sk2(const ConvParams& p, hipStream_t st) {
+    constexpr int KS = 4;
+    const int nchunks = p.Kpad / EV_BK, kbs = nchunks < 8 ? nchunks : 8;
+    const size_t xs = 2 * EV_MAX_TAPS + (size_t)(64 + ((g_xrows_halo + 7) & ~7)) * (32 * kbs + 4);
+    const size_t red = (size_t)(KS - 1) * 4 * 16 * 64, es = (size_t)4 * 32 * 36;
+    size_t smem = std::max(xs, std::max(red, es)) * sizeof(float);
+    if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_sk_kernel<KS, FULL, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((conv_gemm_sk_kernel<KS, FULL, LEAN>), dim3(p.mtiles * p.ntiles), dim3(256 * KS), smem, st, p);
+}
+void launch_sk(const ConvParams& p, hipStream_t st) {
+    static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
+    if (!no_lean && lean_ok(p)) {
+        if (p.act == ACT_SNAKE) launch_sk2<false, 2>(p, st);
+        else if (lean_acc(p)) launch_sk2<false, 3>(p, st);
+        else launch_sk2<false, 1>(p, st);
+    } else if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_sk2<false, 0>(p, st);
+    else launch_sk2<true, 0>(p, st);
 }
 
 int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {
@@ -395,6 +417,12 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     // for Cin <= 128 and for 3-tap layers, 64x192 for the 7 / 11-tap layers at Cin = 256
     if (cfg == 1 && L.Cout % 128 == 0 && !L.sparse_taps && (long)(L.Cout / 64) * ((g.nrows + 127) / 128) >= 256L * 4 * 6)
         cfg = (L.Cin > 128 && L.ntaps >= 7) ? 5 : 0;
+    // launches far below one workgroup per CU with a K loop worth splitting: the 16-wave split-K build (batch-1 decodes)
+    {
+        static const bool no_sk = getenv("EV_NO_SK") != nullptr;
+        const long wg64 = (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64);
+        if (!no_sk && (cfg == 6 || cfg == 8) && wg64 <= 192 && (L.Kpad / EV_BK) * L.ntaps >= 8) cfg = 9;
+    }
     {   // debugging / test override: EV_FORCE_CFG=<0..3> forces one tile configuration for every conv launch
         static const char* env = getenv("EV_FORCE_CFG");
         if (env && *env) cfg = atoi(env);
@@ -442,6 +470,9 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     } else if (cfg == 8) {   // 64 x 64 with register-prefetched X staging
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 64, 2, 2, true>(p, h->stream);
+    } else if (cfg == 9) {   // 64 x 64 tiles, 16 waves, split-K inside the workgroup
+        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_sk(p, h->stream);
     } else if (cfg == 6) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 64, 2, 2>(p, h->stream);

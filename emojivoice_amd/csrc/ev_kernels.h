@@ -300,6 +300,9 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     unsigned yoff = ((unsigned)n0l * p.ldy + co) * 4u, roff = ((unsigned)n0l * p.ldr + co) * 4u;
     const unsigned ystep = (unsigned)(RPP * p.ldy) * 4u, rstep = (unsigned)(RPP * p.ldr) * 4u;
     f32x4 rr[2][NP], ra[ACC ? 2 : 1][ACC ? NP : 1];
+    float rmk[2][NP];                                 // frame-mask values (mask1: before + R, mask2: after), one per row
+    const bool mk = p.mask1 || p.mask2;
+    const __amdgpu_buffer_rsrc_t rM = ev_rsrc(p.rowmask);
     int tt = t;
     unsigned ro = roff, ao = yoff;
     auto issue_r = [&](int set, int jslab) {     // residual (and running-sum) rows of one slab (tt / ro / ao walk along with it)
@@ -309,7 +312,9 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
             const bool ok = co_ok && tt >= 0 && tt < p.T && n < p.nrows && n >= win_lo && n < win_hi;
             f32x4 z = {0.f, 0.f, 0.f, 0.f};
             rr[set][q] = z;
-            if (ok) rr[set][q] = ev_bload4(rR, ro, 0);
+            if (ok && has_r) rr[set][q] = ev_bload4(rR, ro, 0);
+            rmk[set][q] = 1.f;
+            if (ok && mk) rmk[set][q] = ev_bload1(rM, (unsigned)n * 4u, 0);
             if constexpr (ACC) {
                 ra[set][q] = z;
                 if (ok && p.accum) ra[set][q] = ev_bload4(rY, ao, 0);
@@ -319,11 +324,12 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
             ro += rstep;
         }
     };
-    if (has_r) issue_r(0, 0);
+    const bool pre = has_r || mk;
+    if (pre) issue_r(0, 0);
     ev_lds_barrier();                                 // every wave is done reading the X tile: LDS can be reused
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        if (has_r && j + 1 < TN) issue_r((j + 1) & 1, j + 1);
+        if (pre && j + 1 < TN) issue_r((j + 1) & 1, j + 1);
         // per-wave transposition through this wave's private LDS slab (ordered by the wave's own program order)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -346,7 +352,9 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
                 v[0] = fmaxf(v[0], v[0] * p.act_slope); v[1] = fmaxf(v[1], v[1] * p.act_slope);
                 v[2] = fmaxf(v[2], v[2] * p.act_slope); v[3] = fmaxf(v[3], v[3] * p.act_slope);
             }
+            if (p.mask1) v *= rmk[j & 1][q];
             if (has_r) v += rr[j & 1][q];
+            if (p.mask2) v *= rmk[j & 1][q];
             if constexpr (ACC) {
                 v += ra[j & 1][q];
                 if (p.div3) { v[0] = ev_div3(v[0]); v[1] = ev_div3(v[1]); v[2] = ev_div3(v[2]); v[3] = ev_div3(v[3]); }
@@ -679,6 +687,159 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 // never wait for HBM behind their in-order vmcnt — was built and measured 5-30 % SLOWER on every shape: a wave that
 // streams MFMAs back to back starves every dependent instruction chain of the other waves on its SIMD
 // (tools/valu_under_mfma.hip, profiles/r01_valu_under_mfma.log), so the loaders only ran in the MFMA waves' gaps.)
+
+// ---------------------------------------------------------------------------
+// conv_gemm_sk_kernel: the small-launch build.  A batch-1 decode issues ~500 convs of 20-150 tiles each: far fewer
+// workgroups than CUs, every one a serial chain of (HBM latency per 32-channel stage) x (K/32 stages) + K/2 MFMAs of one
+// wave.  Here a workgroup is 4*KS waves: the 64 x 64 tile is still computed by 4 waves of 32 x 32, but KS such groups
+// split the K loop (k-chunk c goes to group c mod KS), all 256*KS threads stage up to eight k-chunks of the X tile at
+// once (one latency episode instead of eight), and the KS partial tiles are summed through LDS in a fixed order
+// (group 0 + 1 + 2 + ...: deterministic) before group 0 runs the usual epilogue.  Same operands and products as
+// conv_gemm_kernel; only the summation order over k-chunks differs.
+// ---------------------------------------------------------------------------
+template <int KS, bool FULL_ACT, int LEAN>
+__global__ __launch_bounds__(256 * KS) void conv_gemm_sk_kernel(const ConvParams p) {
+    constexpr int BM = 64, BN = 64, NTHR = 256 * KS;
+    constexpr int MAXKB = 8;                              // k-chunks staged per round
+    constexpr int MAXPASS = (BN + EV_HALO) * MAXKB * 8 / NTHR;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int2* taps = (int2*)smem;                             // the (<= 16) tap-list entries of this M tile, then the X tile
+    float* Xs = smem + 2 * EV_MAX_TAPS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tw = wave & 3, ks = wave >> 2;
+    const int wm = tw >> 1, wn = tw & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int work = blockIdx.x;
+    const int mt = work % p.mtiles, nt = work / p.mtiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    {   // tiles that contain no storable row (pure padding) do nothing
+        int t_first = (n0 % p.S) - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - (n0 % p.S) + p.P;
+        if (dist >= BN || n0 + dist >= p.nrows) return;
+    }
+    const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
+    const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
+    if (tid < nact) taps[tid] = tl[tid];                  // (published by the first staging barrier)
+    const int nchunks = p.Kpad / EV_BK;
+    const int KBs = nchunks < MAXKB ? nchunks : MAXKB;    // k-chunks per staging round
+    const int LDKs = 32 * KBs + 4;                        // row stride: 4 or 36 (mod 64) floats, conflict-free for ds_read_b128
+    const int xrows = BN + p.halo_lo + p.halo_hi;
+
+    f32x16 acc;
+    {
+        f32x4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bq[g] = z;
+            if constexpr (LEAN != 0) {
+                const int c0 = m0 + wm * 32 + 8 * g + 4 * lh;
+                if (ks == 0 && p.bias && c0 < p.Cout) bq[g] = *(const f32x4*)(p.bias + c0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = bq[r >> 2][r & 3];
+    }
+    const int mt32 = (m0 + wm * 32) >> 5;
+    const int KG8 = p.Kpad >> 3;
+    const __amdgpu_buffer_rsrc_t rW = ev_rsrc(p.W), rX = ev_rsrc(p.X);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned wbase = (unsigned)(mt32 * KG8) * 1024u;
+    const int f4row = KBs * 8;                            // float4 per staged row
+    const int nf4 = xrows * f4row;
+
+    for (int c0 = 0; c0 < nchunks; c0 += KBs) {
+        const int kb = (nchunks - c0 < KBs) ? nchunks - c0 : KBs;
+        ev_lds_barrier();                                 // the previous round's MFMAs are done with Xs
+        {   // ---- all threads stage kb chunks of the X tile: loads first, then (prologue +) LDS writes
+            f32x4 xv[MAXPASS];
+#pragma unroll
+            for (int q = 0; q < MAXPASS; ++q) {
+                const int i = q * NTHR + tid;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (i < nf4) {
+                    const int r = i / f4row, c = (c0 * 8 + (i % f4row)) * 4;
+                    const int gr = n0 - p.halo_lo + r;
+                    if (c < p.Cin && (i % f4row) < kb * 8 && gr >= 0 && gr < p.nrows) {
+                        const unsigned xcol = (unsigned)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1));
+                        v = ev_bload4(rX, ((unsigned)gr * p.ldx + xcol) * 4u, 0);
+                    }
+                }
+                xv[q] = v;
+            }
+#pragma unroll
+            for (int q = 0; q < MAXPASS; ++q) {
+                const int i = q * NTHR + tid;
+                if (i < nf4) {
+                    f32x4 v = xv[q];
+                    if (p.pro_lrelu) {
+                        v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                        v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                    }
+                    *(f32x4*)(Xs + (i / f4row) * LDKs + (i % f4row) * 4) = v;
+                }
+            }
+        }
+        ev_lds_barrier();
+        // ---- this wave group's chunks of the round (c = ks, ks + KS, ...) x taps, weight fragments one step ahead
+        const int nmy = (kb > ks) ? ((kb - ks + KS - 1) / KS) * nact : 0;
+        f32x4 an0, an1, an2, an3;
+        int2 tvn = make_int2(0, 0);
+        int cn = ks;
+        if (nmy > 0) {
+            tvn = ev_uniform(taps[0]);
+            const unsigned ap = (unsigned)tvn.x + wbase + (unsigned)((c0 + cn) * 4) * 1024u;
+            an0 = ev_bload4(rW, wlane, ap); an1 = ev_bload4(rW, wlane, ap + 1024u);
+            an2 = ev_bload4(rW, wlane, ap + 2048u); an3 = ev_bload4(rW, wlane, ap + 3072u);
+        }
+        int ti = 0;
+        for (int it = 0; it < nmy; ++it) {
+            const int2 tv = tvn;
+            const int c = cn;
+            const f32x4 a0 = an0, a1 = an1, a2 = an2, a3 = an3;
+            if (++ti == nact) { ti = 0; cn += KS; }
+            if (it + 1 < nmy) {
+                tvn = ev_uniform(taps[ti]);
+                const unsigned ap = (unsigned)tvn.x + wbase + (unsigned)((c0 + cn) * 4) * 1024u;
+                an0 = ev_bload4(rW, wlane, ap); an1 = ev_bload4(rW, wlane, ap + 1024u);
+                an2 = ev_bload4(rW, wlane, ap + 2048u); an3 = ev_bload4(rW, wlane, ap + 3072u);
+            }
+            const float* brow = Xs + (wn * 32 + li + p.halo_lo + tv.y) * LDKs + 4 * lh + c * 32;
+            const f32x4 b0 = *(const f32x4*)(brow), b1 = *(const f32x4*)(brow + 8);
+            const f32x4 b2 = *(const f32x4*)(brow + 16), b3 = *(const f32x4*)(brow + 24);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], b0[s4], acc, 0, 0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], b1[s4], acc, 0, 0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s4], b2[s4], acc, 0, 0, 0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s4], b3[s4], acc, 0, 0, 0);
+        }
+    }
+    // ---- sum the KS partial tiles through LDS (aliases the X tile), fixed order
+    ev_lds_barrier();
+    float* red = smem;                                    // [KS-1][4 tiles][16 regs][64 lanes]
+    if (ks > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(((ks - 1) * 4 + tw) * 16 + r) * 64 + lane] = acc[r];
+    }
+    ev_lds_barrier();
+    if (ks > 0) return;                                   // s_barrier only counts surviving waves from here on
+#pragma unroll
+    for (int k = 1; k < KS; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] += red[(((k - 1) * 4 + tw) * 16 + r) * 64 + lane];
+    f32x16 accs[1][1];
+    accs[0][0] = acc;
+    if constexpr (LEAN != 0) conv_epilogue_lean<1, 1, LEAN>(p, accs, smem + tw * (32 * 36), m0 + wm * 32, n0 + wn * 32, lane);
+    else conv_epilogue<1, 1, FULL_ACT>(p, accs, smem + tw * (32 * 36), m0 + wm * 32, n0 + wn * 32, lane);
+}
 
 // ---------------------------------------------------------------------------
 // resblock_pair_kernel: one (c1, c2) pair of HiFi-GAN ResBlock1 (hifigan/models.py:90-97) in ONE launch:

@@ -132,7 +132,7 @@ def test_config2_shape_properties(model, vocoder):
     wav = vocoder(mel)
     assert wav.shape == (B, 1, 256 * Tp)
     wav1 = vocoder(mel[2:3])
-    assert _linf(wav[2:3], wav1.cpu()) <= 1e-5
+    assert _linf(wav[2:3], wav1.cpu()) <= 5e-5     # the batch-1 call takes the split-K build for its small launches: other k-chunk summation order
     assert torch.isfinite(wav).all()
 
 
@@ -239,7 +239,7 @@ def test_vocoder_batch_chunking_matches(vocoder):
     mel = (torch.randn(5, 80, 24, generator=g) * 2 - 5).cuda()
     full = vocoder(mel)
     parts = torch.cat([vocoder(mel[:2]), vocoder(mel[2:])], dim=0)
-    assert _linf(full, parts.cpu()) <= 1e-6
+    assert _linf(full, parts.cpu()) <= 5e-5      # tiny chunks take the split-K build for some layers: other k-chunk summation order
 
 
 def test_batch_pipeline_is_bit_identical(model, vocoder):
