@@ -447,10 +447,6 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         const int slots = cfg == 0 ? 3 : ((cfg == 1 || cfg == 5 || cfg == 7) ? 4 : ((cfg == 6 || cfg == 8) ? 5 : 3));
         const long wgs = (cfg == 5 || cfg == 7) ? (long)((L.Cout + 63) / 64) * ((g.nrows + 191) / 192) : (cfg == 6 || cfg == 8) ? (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64) : cfg == 0 ? (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) : (cfg == 1 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) : (long)((L.Cout + 31) / 32) * ((g.nrows + 255) / 256));
         p.stagger_slots = (wgs >= 256L * slots * 3) ? slots : 0;
-        {   // experiment: EV_PHASE=<q> staggers the co-resident workgroups of single-round launches by q/4 MFMA phases each
-            static const char* penv = getenv("EV_PHASE");
-            if (penv && *penv && wgs <= 256L * 6) p.stagger_slots = -atoi(penv);
-        }
         if (e.stagger >= 0) p.stagger_slots = e.stagger;
         static const char* senv = getenv("EV_STAGGER");
         if (senv && *senv) p.stagger_slots = atoi(senv) ? p.stagger_slots : 0;

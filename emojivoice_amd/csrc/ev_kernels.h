@@ -420,15 +420,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     // then its memory-bound epilogues at the same time.  Delaying the k-th co-resident workgroup of the FIRST wave of
     // workgroups by k/slots of one tile time puts (and keeps) them out of phase: one streams its epilogue while the
     // others feed the matrix pipe.
-    if (p.stagger_slots < 0) {
-        // single-round launches: every CU holds its 2-5 workgroups from t = 0 to the end, all in the same phase (they
-        // stage together, then compete for the matrix pipe together).  Offsetting co-resident workgroup k by k MFMA
-        // phases (one k-chunk of one wave) interleaves them: one feeds the pipe while the others stage.
-        const int slot = blockIdx.x >> 8;
-        const long wait = (long)nact * (16L * TM * TN * 64) * slot * (-p.stagger_slots) / 4;
-        const long long t0 = __builtin_amdgcn_s_memtime();
-        while ((long)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(8);
-    } else if (p.stagger_slots > 1 && (int)blockIdx.x < 256 * p.stagger_slots) {
+    if (p.stagger_slots > 1 && (int)blockIdx.x < 256 * p.stagger_slots) {
         const int slot = blockIdx.x >> 8;
         const long tile_cycles = (long)(p.Kpad / EV_BK) * nact * (16L * TM * TN * 64) * p.stagger_slots;
         const long wait = tile_cycles * slot / p.stagger_slots;
@@ -1488,19 +1480,6 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float* QKV, in
         o.x /= l; o.y /= l;
     }
     if (act) *(float2*)(O + (row0 + tq) * ldo + dq) = o;
-}
-
-// sinusoidal time embedding (decoder.py:14-29) for a list of times: emb[i][0:half] = sin, [half:] = cos
-__global__ void time_sinusoid_kernel(const float* tvals, float* emb, int nt, int dim, float scale) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    int half = dim / 2;
-    if (idx >= nt * half) return;
-    int i = idx / half, k = idx % half;
-    float e = logf(10000.0f) / (float)(half - 1);
-    float f = expf((float)k * -e);
-    float a = (scale * tvals[i]) * f;
-    emb[(size_t)i * dim + k] = sinf(a);
-    emb[(size_t)i * dim + half + k] = cosf(a);
 }
 
 // conv_post (hifigan/models.py:195-196: Conv1d(C, 1, K, padding = K/2) + tanh) straight into the (B, T) waveform.  One
