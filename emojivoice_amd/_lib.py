@@ -20,6 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 EXPORTS = [
     "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder", "ev_load_text_encoder", "ev_text_encoder",
+    "ev_stft_magnitude", "ev_denoise",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention",
 ]
@@ -81,6 +82,8 @@ def load_library() -> C.CDLL:
     lib.ev_estimator.argtypes = [vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]
     lib.ev_hifigan.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.ev_text_encoder.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.ev_stft_magnitude.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.ev_denoise.argtypes = [vp, vp, i32, i32, vp, f32, vp, vp]
     lib.ev_profile_enable.argtypes = [vp, i32]
     lib.ev_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     lib.ev_op_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
@@ -155,6 +158,24 @@ class Engine:
 
     def load_vocoder(self, tensors: Dict[str, torch.Tensor]):
         self._load(self.lib.ev_load_vocoder, tensors, "ev_load_vocoder")
+
+    def stft_magnitude(self, audio):
+        """|STFT| (B, 513, L/256 + 1) of (B, L) audio with the denoiser's STFT (denoiser.py:36-56)."""
+        audio = self._f32(audio)
+        B, L = audio.shape
+        mag = torch.empty((B, 513, L // 256 + 1), dtype=torch.float32, device=audio.device)
+        self._check(self.lib.ev_stft_magnitude(self.h, audio.data_ptr(), B, L, mag.data_ptr(), _stream_ptr()), "ev_stft_magnitude")
+        return mag
+
+    def denoise(self, audio, bias_spec, strength: float):
+        """Denoiser.forward (denoiser.py:58-64) on (B, L) audio; bias_spec (513,)."""
+        audio = self._f32(audio)
+        B, L = audio.shape
+        bias = self._f32(bias_spec).reshape(-1)
+        assert bias.numel() == 513
+        out = torch.empty_like(audio)
+        self._check(self.lib.ev_denoise(self.h, audio.data_ptr(), B, L, bias.data_ptr(), float(strength), out.data_ptr(), _stream_ptr()), "ev_denoise")
+        return out
 
     def load_text_encoder(self, tensors: Dict[str, torch.Tensor]):
         self._load(self.lib.ev_load_text_encoder, tensors, "ev_load_text_encoder")

@@ -84,6 +84,9 @@ struct TextEncW {
     ConvLayer proj_m, dp1, dp2, dp_proj; float *dp_g1, *dp_b1, *dp_g2, *dp_b2;
 };
 
+// Denoiser STFT pair (hifigan/denoiser.py): windowed DFT bases as two 4-tap convolutions over rows of 256 samples
+struct DenoiserW { bool ready = false; ConvLayer fwd, inv; float* win2 = nullptr; };
+
 }  // namespace
 
 struct ev_handle {
@@ -94,6 +97,8 @@ struct ev_handle {
     EstimatorW est;
     VocoderW voc;
     TextEncW enc;
+    DenoiserW dn;
+    char* dn_ws = nullptr; size_t dn_ws_bytes = 0;
     char* enc_ws = nullptr; size_t enc_ws_bytes = 0;   // the text encoder's own (small) workspace
     // workspace
     char* ws = nullptr; size_t ws_bytes = 0; size_t ws_used = 0;
@@ -913,6 +918,94 @@ int run_text_encoder(ev_handle* h, const int64_t* d_ids, const int32_t* d_len, c
     return 0;
 }
 
+// Build the two DFT-basis layers once (double-precision trigonometry, rounded to fp32).
+int denoiser_init(ev_handle* h) {
+    DenoiserW& w = h->dn;
+    if (w.ready) return 0;
+    const int N = 1024, NB = 513, HC = 516;                   // bins padded to 516 per half: [re | im] = 1032 columns
+    const double PI = 3.14159265358979323846;
+    std::vector<double> win(N);
+    for (int n = 0; n < N; ++n) win[n] = 0.5 - 0.5 * cos(2.0 * PI * n / N);       // torch.hann_window(1024), periodic
+    {   // forward: out[f][k] = sum_n w[n] a[256 f + n] e^{-2 pi i k n / N}; taps j = 0..3 over rows f + j, 256 columns each
+        ConvLayer& L = w.fwd;
+        L.Cin = 256; L.Cout = 2 * HC; L.ntaps = 4; L.Mpad = round_up(L.Cout, 128); L.Kpad = 256;
+        for (int j = 0; j < 4; ++j) L.off[j] = j;
+        std::vector<float> Wh((size_t)4 * L.Mpad * L.Kpad, 0.f);
+        for (int j = 0; j < 4; ++j)
+            for (int k = 0; k < NB; ++k)
+                for (int c = 0; c < 256; ++c) {
+                    const int n = 256 * j + c;
+                    const double ang = 2.0 * PI * (double)((long)k * n % N) / N;
+                    Wh[((size_t)j * L.Mpad + k) * L.Kpad + c] = (float)(win[n] * cos(ang));
+                    Wh[((size_t)j * L.Mpad + HC + k) * L.Kpad + c] = (float)(-win[n] * sin(ang));
+                }
+        L.macs_per_row = (double)2 * NB * N;
+        if (finish_layer(h, L, Wh, nullptr)) return 1;
+    }
+    {   // inverse + overlap-add: row r, column c <- sum_j frame (r - j), sample n = 256 j + c of w[n] * irfft(X)[n]
+        ConvLayer& L = w.inv;
+        L.Cin = 2 * HC; L.Cout = 256; L.ntaps = 4; L.Mpad = round_up(L.Cout, 128); L.Kpad = round_up(L.Cin, EV_BK);
+        for (int j = 0; j < 4; ++j) L.off[j] = -j;
+        std::vector<float> Wh((size_t)4 * L.Mpad * L.Kpad, 0.f);
+        for (int j = 0; j < 4; ++j)
+            for (int c = 0; c < 256; ++c) {
+                const int n = 256 * j + c;
+                for (int k = 0; k < NB; ++k) {
+                    const double ck = (k == 0 || k == N / 2) ? 1.0 : 2.0;
+                    const double ang = 2.0 * PI * (double)((long)k * n % N) / N;
+                    Wh[((size_t)j * L.Mpad + c) * L.Kpad + k] = (float)(win[n] * ck * cos(ang) / N);
+                    if (k != 0 && k != N / 2) Wh[((size_t)j * L.Mpad + c) * L.Kpad + HC + k] = (float)(-win[n] * ck * sin(ang) / N);
+                }
+            }
+        L.macs_per_row = (double)2 * NB * N;
+        if (finish_layer(h, L, Wh, nullptr)) return 1;
+    }
+    std::vector<float> w2(N);
+    for (int n = 0; n < N; ++n) w2[n] = (float)(win[n] * win[n]);
+    if (dev_upload(h, w2, &w.win2)) return 1;
+    w.ready = true;
+    return 0;
+}
+
+// STFT -> (optional magnitude output) -> (optional spectral gain + inverse STFT)
+int run_denoiser(ev_handle* h, const float* d_audio, int B, int L, const float* d_bias, float strength, float* d_out, float* d_mag) {
+    if (denoiser_init(h)) return 1;
+    const DenoiserW& w = h->dn;
+    const int T = L / 256, R = T + 4, F = T + 1, P = 4, S = R + 2 * P;
+    const Geom g{B * S, S, P, R};
+    const size_t n = (size_t)g.nrows;
+    const size_t need = (n * (256 + 1032 + 256) + 1024) * sizeof(float);
+    if (need > h->dn_ws_bytes) {
+        HIPCHK(h, hipDeviceSynchronize());
+        if (h->dn_ws) HIPCHK(h, hipFree(h->dn_ws));
+        h->dn_ws = nullptr; h->dn_ws_bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&h->dn_ws, need));
+        h->dn_ws_bytes = need;
+    }
+    HIPCHK(h, hipMemsetAsync(h->dn_ws, 0, need, h->stream));
+    Bump bp; bp.base = h->dn_ws; bp.off = 0;
+    float* SIG = bp.take(n * 256); float* SPEC = bp.take(n * 1032); float* OUT = bp.take(n * 256);
+    hipStream_t st = h->stream;
+    {
+        const size_t tot = (size_t)B * (L + 1024);
+        hipLaunchKernelGGL(dn_pad_reflect_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_audio, SIG, B, L, S, P);
+    }
+    { Epi e; if (launch_conv(h, w.fwd, SIG, 256, SPEC, 1032, g, e)) return 1; }
+    {
+        const size_t tot = n * 516;
+        hipLaunchKernelGGL(dn_gain_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, SPEC, d_bias, strength, d_mag, g.nrows, S, P, F);
+    }
+    HIPCHK(h, hipGetLastError());
+    if (!d_out) return 0;
+    { Epi e; if (launch_conv(h, w.inv, SPEC, 1032, OUT, 256, g, e)) return 1; }
+    {
+        const size_t tot = (size_t)B * L;
+        hipLaunchKernelGGL(dn_crop_norm_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, (const float*)OUT, (const float*)w.win2, d_out, B, L, S, P, F);
+    }
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 }  // namespace
 
 // ===========================================================================
@@ -949,6 +1042,7 @@ void ev_destroy(ev_handle* h) {
     if (h->ws) hipFree(h->ws);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->enc_ws) hipFree(h->enc_ws);
+    if (h->dn_ws) hipFree(h->dn_ws);
     for (int i = 0; i < 2; ++i) { if (h->temb_ev[i]) hipEventDestroy(h->temb_ev[i]); if (h->temb_host[i]) hipHostFree(h->temb_host[i]); }
     delete h;
 }
@@ -1250,6 +1344,23 @@ int ev_estimator(ev_handle* h, const float* d_x, const float* d_mu, const int32_
     hipLaunchKernelGGL(fm_to_cm_kernel, grid, dim3(256), 0, h->stream, (const float*)b.V0, 80, 0, d_v, 80, Tp, b.g0.S, b.g0.P, 1.0f, 0.0f);
     HIPCHK(h, hipGetLastError());
     return 0;
+}
+
+int ev_stft_magnitude(ev_handle* h, const float* d_audio, int B, int L, float* d_mag, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (B <= 0 || L < 1024 || (L & 255) || !d_audio || !d_mag) return fail(h, "bad arguments B=%d L=%d (L must be a multiple of 256, >= 1024)", B, L);
+    h->stream = (hipStream_t)stream;
+    return run_denoiser(h, d_audio, B, L, nullptr, 0.f, nullptr, d_mag);
+}
+
+int ev_denoise(ev_handle* h, const float* d_audio, int B, int L, const float* d_bias_spec, float strength, float* d_out, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (B <= 0 || L < 1024 || (L & 255) || !d_audio || !d_bias_spec || !d_out) return fail(h, "bad arguments B=%d L=%d (L must be a multiple of 256, >= 1024)", B, L);
+    if ((double)B * (L / 256 + 12) * 1032 * 4.0 >= 4294967296.0) return fail(h, "audio batch exceeds the 4 GiB buffer-addressing limit: split the batch");
+    h->stream = (hipStream_t)stream;
+    return run_denoiser(h, d_audio, B, L, d_bias_spec, strength, d_out, nullptr);
 }
 
 int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, void* stream) {

@@ -1482,6 +1482,56 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float* QKV, in
     if (act) *(float2*)(O + (row0 + tq) * ldo + dq) = o;
 }
 
+// ---------------------------------------------------------------------------
+// Denoiser (hifigan/denoiser.py) support kernels.  The STFT / inverse STFT (n_fft 1024, hop 256, periodic Hann window,
+// centred with reflect padding — torch.stft / torch.istft defaults as the reference calls them) are two convolutions on
+// conv_gemm_kernel over the padded signal viewed as rows of 256 samples: frame f = rows f .. f+3 (4 taps, 256 "channels")
+// against the windowed DFT basis; the inverse is the transposed basis with taps 0, -1, -2, -3 (overlap-add).
+// ---------------------------------------------------------------------------
+// (B, L) audio -> rows of 256 samples of the reflect-padded signal (pad 512 each side), frame-major padded layout
+__global__ void dn_pad_reflect_kernel(const float* audio, float* rows, int B, int L, int S, int P) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Lp = L + 1024;
+    if (idx >= (size_t)B * Lp) return;
+    const int b = (int)(idx / Lp), m = (int)(idx % Lp);
+    int i = m - 512;
+    if (i < 0) i = -i;
+    else if (i >= L) i = 2 * (L - 1) - i;
+    rows[((size_t)b * S + P) * 256 + m] = audio[(size_t)b * L + i];
+}
+
+// spectral gain of denoiser.py:58-64 on [re(516) | im(516)] rows: mag' = clamp(|X| - bias*strength, 0), X' = mag' * exp(i*angle(X))
+// = X * mag'/|X| (and mag' for |X| = 0: angle 0).  Rows that are not frames (f >= F, pads) are zeroed.  mag_out (optional): |X|.
+__global__ void dn_gain_kernel(float* spec, const float* bias, float strength, float* mag_out, int nrows, int S, int P, int F) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)nrows * 516) return;
+    const int n = (int)(idx / 516), k = (int)(idx % 516);
+    const int f = (n % S) - P;
+    float* row = spec + (size_t)n * 1032;
+    if (f < 0 || f >= F || k >= 513) { row[k] = 0.f; row[516 + k] = 0.f; return; }
+    const float re = row[k], im = row[516 + k];
+    const float mag = sqrtf(re * re + im * im);
+    if (mag_out) mag_out[((size_t)(n / S) * 513 + k) * F + f] = mag;
+    if (!bias) return;
+    const float m2 = fmaxf(mag - bias[k] * strength, 0.f);
+    if (mag > 0.f) { const float g = m2 / mag; row[k] = re * g; row[516 + k] = im * g; }
+    else { row[k] = m2; row[516 + k] = 0.f; }
+}
+
+// overlap-added rows -> (B, L): drop the 512-sample centre padding and divide by the window envelope sum_f w^2[m - 256 f]
+// over the frames f in [0, F) that cover padded sample m (torch.istft's normalisation)
+__global__ void dn_crop_norm_kernel(const float* rows, const float* win2, float* out, int B, int L, int S, int P, int F) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * L) return;
+    const int b = (int)(idx / L), i = (int)(idx % L);
+    const int m = i + 512, r = m >> 8, c = m & 255;
+    float env = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int f = r - j; if (f >= 0 && f < F) env += win2[256 * j + c]; }
+    const float v = rows[((size_t)b * S + P + r) * 256 + c];
+    out[idx] = env > 1e-11f ? v / env : v;
+}
+
 // conv_post (hifigan/models.py:195-196: Conv1d(C, 1, K, padding = K/2) + tanh) straight into the (B, T) waveform.  One
 // output channel makes this a sliding dot product, not a GEMM: a 32-row MFMA tile would waste 31/32 of the matrix
 // pipe and the launch was latency-bound at ~0.65 TB/s.  Here a workgroup stages 256 + K - 1 frames x C channels in LDS

@@ -106,6 +106,15 @@ int ev_text_encoder(ev_handle *h, const int64_t *d_ids, const int32_t *d_lengths
 /* HiFi-GAN V1 generator: d_mel (B, 80, T) -> d_wav (B, 256*T), tanh output, no clamp/denoiser. */
 int ev_hifigan(ev_handle *h, const float *d_mel, int B, int T, float *d_wav, void *stream);
 
+/* Denoiser stage that every reference caller applies to the vocoder output (hifigan/denoiser.py:10-64; cli.py:121-126,
+ * feel_me.py:181-187): torch.stft / torch.istft semantics at n_fft = win = 1024, hop 256, periodic Hann window, centred
+ * with reflect padding, evaluated as two DFT-basis convolutions on the matrix cores.
+ *   ev_stft_magnitude: d_audio (B, L) -> d_mag (B, 513, L/256 + 1)     (Denoiser.__init__'s bias spectrum)
+ *   ev_denoise:        d_out = ISTFT(clamp(|X| - bias*strength, 0) * exp(i*angle(X))), X = STFT(d_audio); d_bias_spec (513)
+ * L must be a multiple of 256 (it is 256 * mel frames) and >= 1024. */
+int ev_stft_magnitude(ev_handle *h, const float *d_audio, int B, int L, float *d_mag, void *stream);
+int ev_denoise(ev_handle *h, const float *d_audio, int B, int L, const float *d_bias_spec, float strength, float *d_out, void *stream);
+
 /* Timing hooks for bench.py: HIP-event time (ms) of the dominant kernel family
  * (fp32-MFMA implicit-GEMM conv) accumulated over the calls since the last reset,
  * measured on the stream the kernels run on. */

@@ -283,3 +283,21 @@ def test_device_text_encoder_vs_golden_and_host(golden, model, matcha_sd):
     assert _linf(mu2, rmu) <= 1e-4 and _linf(logw2, rlogw) <= 1e-4
     hmu, hlogw, _ = model.encoder(ids2.cuda(), lens2.cuda(), spk2)
     assert _linf(mu2, hmu.cpu()) <= 1e-4 and _linf(logw2, hlogw.cpu()) <= 1e-4
+
+
+def test_denoiser_vs_oracle_batched(vocoder):
+    """ev_denoise / ev_stft_magnitude (DFT-basis convolutions) vs torch.stft / torch.istft in the oracle on a ragged-content
+    batch, including the shortest supported length (4 hops) and the magnitude spectrum itself."""
+    vocoder._sync_engine()
+    eng = vocoder.engine
+    g = torch.Generator().manual_seed(77)
+    for B, L in ((3, 256 * 21), (1, 1024)):
+        audio = (torch.randn(B, L, generator=g) * 0.3).clamp(-1, 1)
+        bias = torch.rand(513, generator=g) * 2.0
+        ref_spec = torch.stft(audio, n_fft=1024, hop_length=256, win_length=1024, window=torch.hann_window(1024), return_complex=True)
+        mag = eng.stft_magnitude(audio.cuda())
+        assert tuple(mag.shape) == tuple(ref_spec.shape)
+        assert _linf(mag, ref_spec.abs()) <= 2e-4 * float(ref_spec.abs().max())
+        ref = O.denoiser(audio, bias[None, :, None], strength=0.01)
+        got = eng.denoise(audio.cuda(), bias.cuda(), 0.01)
+        assert _linf(got, ref) <= 2e-5
