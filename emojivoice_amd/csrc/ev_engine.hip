@@ -60,6 +60,9 @@ struct EstimatorW {
     int in_ch = 0;  // 224 (or 160 single-speaker)
     ConvLayer t1, t2, tmlp;  // time MLP: linear_1 (+SiLU), linear_2 (+Mish), 6 stacked resnet mlps
     ResnetW rn[6];           // down0, down1, mid0, mid1, up0, up1
+    // rn[0] consumes [x | mu | spk] (decoder.py:405-407): mu and spk do not change over the Euler steps, so their share of
+    // block1's conv and of res_conv (incl. the biases) is computed once per decode and added as a residual to the x share
+    ConvLayer rn0_c1_x, rn0_c1_ms, rn0_res_x, rn0_res_ms;
     TransW tr[6];
     ConvLayer down0, down1, up0, up1, fin_conv, fin_proj;
     float *fin_g, *fin_b;
@@ -609,6 +612,7 @@ struct EstBufs {
     float *rm0, *rm1, *X0, *state, *A0, *B0, *R0, *H0, *LN0, *QKV0, *ATT0, *FF0, *CAT1, *U1, *F0, *G0, *V0;
     float *A1, *B1, *R1, *H1, *LN1, *QKV1, *ATT1, *FF1, *CAT0, *D1, *D2, *M1, *UU;
     float *tv, *temb_in, *temb_a, *temb_b, *tproj;
+    float *C1MS, *RMS;   // time-invariant (mu, spk) share of rn[0].block1 conv / res_conv
 };
 
 void plan_est(Bump& b, int B, int Tp, int in_ch, int nsteps, EstBufs& e) {
@@ -625,6 +629,7 @@ void plan_est(Bump& b, int B, int Tp, int in_ch, int nsteps, EstBufs& e) {
     e.QKV1 = b.take(n1 * 384); e.ATT1 = b.take(n1 * 128); e.FF1 = b.take(n1 * 1024); e.CAT0 = b.take(n1 * 512);
     e.D1 = b.take(n1 * 256); e.D2 = b.take(n1 * 256); e.M1 = b.take(n1 * 256); e.UU = b.take(n1 * 256);
     const size_t ns = nsteps;
+    e.C1MS = b.take(n0 * 256); e.RMS = b.take(n0 * 256);
     e.tv = b.take(ns); e.temb_in = b.take(ns * in_ch); e.temb_a = b.take(ns * 1024); e.temb_b = b.take(ns * 1024); e.tproj = b.take(ns * 1536);
 }
 
@@ -706,6 +711,17 @@ int run_resnet(ev_handle* h, const ResnetW& w, const float* X, int ldx, const Le
     return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.R, 256, L.g, 256, 2);
 }
 
+// rn[0] with the time-invariant input share hoisted out of the Euler loop (see EstimatorW): X = X0 (x in columns [0, n_feats))
+int run_resnet0(ev_handle* h, const EstimatorW& W, const float* X, int ldx, const LevelBufs& L, const float* temb, const float* C1MS, const float* RMS) {
+    const ResnetW& w = W.rn[0];
+    Epi e;
+    { Epi e1; e1.R = C1MS; e1.ldr = 256; if (launch_conv(h, W.rn0_c1_x, X, ldx, L.A, 256, L.g, e1)) return 1; }
+    if (launch_gn(h, L.A, 256, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1)) return 1;
+    if (launch_conv(h, w.c2, L.Bf, 256, L.A, 256, L.g, e)) return 1;
+    { Epi e2; e2.R = RMS; e2.ldr = 256; if (launch_conv(h, W.rn0_res_x, X, ldx, L.R, 256, L.g, e2)) return 1; }
+    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.R, 256, L.g, 256, 2);
+}
+
 // BasicTransformerBlock (transformer.py:243-316) on L.H; result (masked) -> Z with row stride ldz
 int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z, int ldz, int heads) {
     Epi e;
@@ -729,7 +745,7 @@ int run_estimator(ev_handle* h, EstBufs& b, int step, float dt, bool euler) {
     LevelBufs L1{b.A1, b.B1, b.R1, b.H1, b.LN1, b.QKV1, b.ATT1, b.FF1, b.rm1, b.g1};
     const float* tp = b.tproj + (size_t)step * 1536;
     // down 0 @T
-    if (run_resnet(h, w.rn[0], b.X0, w.in_ch, L0, tp + 0 * 256)) return 1;
+    if (run_resnet0(h, w, b.X0, w.in_ch, L0, tp + 0 * 256, b.C1MS, b.RMS)) return 1;
     if (run_transformer(h, w.tr[0], L0, b.CAT1 + 256, 512, heads)) return 1;      // hidden 0
     {   // Downsample1D k3 s2 p1 over the pair view of CAT1[:, 256:512]
         Epi e; e.isplit_log2 = 8; e.isstride = 512; e.mask1 = 1; e.rowmask = b.rm1;
@@ -822,6 +838,12 @@ int prep_inputs(ev_handle* h, EstBufs& b, const float* d_x, const float* d_mu, c
         hipLaunchKernelGGL(bcast_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_spk, b.X0, w.in_ch, 160, C, b.g0.nrows, b.g0.S, b.g0.P, b.g0.T, (const float*)b.rm0);
     }
     HIPCHK(h, hipGetLastError());
+    {   // time-invariant share of rn[0]: columns [n_feats, in_ch) of X0 = [mu*m | spk*m]
+        const int nf = h->dims.n_feats;
+        Epi e;
+        if (launch_conv(h, w.rn0_c1_ms, b.X0 + nf, w.in_ch, b.C1MS, 256, b.g0, e)) return 1;
+        if (launch_conv(h, w.rn0_res_ms, b.X0 + nf, w.in_ch, b.RMS, 256, b.g0, e)) return 1;
+    }
     return 0;
 }
 
@@ -1096,6 +1118,24 @@ int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* in
         REQ(pack_conv(h, w.rn[i].c1, *c1w, c1b, 1));
         REQ(pack_conv(h, w.rn[i].c2, *c2w, c2b, 1));
         REQ(pack_conv(h, w.rn[i].res, *rw, rb, 1));
+        if (i == 0) {   // split along Cin at n_feats: [x | mu, spk]
+            auto slice = [&](const HostTensor& t, int c0, int c1, std::vector<float>& store, HostTensor& out) {
+                const int Co = (int)t.shape[0], Ci = (int)t.shape[1], K = t.ndim == 3 ? (int)t.shape[2] : 1;
+                store.resize((size_t)Co * (c1 - c0) * K);
+                for (int co = 0; co < Co; ++co)
+                    for (int ci = c0; ci < c1; ++ci)
+                        for (int k = 0; k < K; ++k) store[((size_t)co * (c1 - c0) + (ci - c0)) * K + k] = t.p[((size_t)co * Ci + ci) * K + k];
+                out = t; out.p = store.data(); out.shape[1] = c1 - c0;
+            };
+            const int nf = h->dims.n_feats, cin = (int)c1w->shape[1];
+            std::vector<float> s1, s2, s3, s4;
+            HostTensor a, bms, c, dms;
+            slice(*c1w, 0, nf, s1, a); slice(*c1w, nf, cin, s2, bms); slice(*rw, 0, nf, s3, c); slice(*rw, nf, cin, s4, dms);
+            REQ(pack_conv(h, w.rn0_c1_x, a, nullptr, 1));
+            REQ(pack_conv(h, w.rn0_c1_ms, bms, c1b, 1));
+            REQ(pack_conv(h, w.rn0_res_x, c, nullptr, 1));
+            REQ(pack_conv(h, w.rn0_res_ms, dms, rb, 1));
+        }
         REQ(upload_vec(h, m, p + ".block1.block.1.weight", &w.rn[i].g1));
         REQ(upload_vec(h, m, p + ".block1.block.1.bias", &w.rn[i].b1));
         REQ(upload_vec(h, m, p + ".block2.block.1.weight", &w.rn[i].g2));
