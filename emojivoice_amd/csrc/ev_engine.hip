@@ -52,7 +52,9 @@ struct Epi {
     int osplit_log2 = 31, osstride = 0;     // output column split
 };
 
-struct ResnetW { ConvLayer c1, c2, res; float *g1, *b1, *g2, *b2; };
+// c1r = block1's conv (k = 3) and res_conv (1x1, centre tap only) of one ResnetBlock1D stacked along the output axis:
+// both read the same input, so one launch stages it once; the res half's M tiles carry a one-entry tap list
+struct ResnetW { ConvLayer c1r, c2; float *g1, *b1, *g2, *b2; };
 struct TransW { ConvLayer qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln3g, *ln3b, *alpha, *binv; };
 
 struct EstimatorW {
@@ -62,7 +64,7 @@ struct EstimatorW {
     ResnetW rn[6];           // down0, down1, mid0, mid1, up0, up1
     // rn[0] consumes [x | mu | spk] (decoder.py:405-407): mu and spk do not change over the Euler steps, so their share of
     // block1's conv and of res_conv (incl. the biases) is computed once per decode and added as a residual to the x share
-    ConvLayer rn0_c1_x, rn0_c1_ms, rn0_res_x, rn0_res_ms;
+    ConvLayer rn0_c1r_x, rn0_c1r_ms;
     TransW tr[6];
     ConvLayer down0, down1, up0, up1, fin_conv, fin_proj;
     float *fin_g, *fin_b;
@@ -612,7 +614,8 @@ struct EstBufs {
     float *rm0, *rm1, *X0, *state, *A0, *B0, *R0, *H0, *LN0, *QKV0, *ATT0, *FF0, *CAT1, *U1, *F0, *G0, *V0;
     float *A1, *B1, *R1, *H1, *LN1, *QKV1, *ATT1, *FF1, *CAT0, *D1, *D2, *M1, *UU;
     float *tv, *temb_in, *temb_a, *temb_b, *tproj;
-    float *C1MS, *RMS;   // time-invariant (mu, spk) share of rn[0].block1 conv / res_conv
+    float *C1RMS;        // time-invariant (mu, spk) share of rn[0]'s [block1 conv | res_conv], 512 wide
+    float *AR0, *AR1;    // [block1 conv | res_conv] outputs per level, 512 wide
 };
 
 void plan_est(Bump& b, int B, int Tp, int in_ch, int nsteps, EstBufs& e) {
@@ -629,7 +632,7 @@ void plan_est(Bump& b, int B, int Tp, int in_ch, int nsteps, EstBufs& e) {
     e.QKV1 = b.take(n1 * 384); e.ATT1 = b.take(n1 * 128); e.FF1 = b.take(n1 * 1024); e.CAT0 = b.take(n1 * 512);
     e.D1 = b.take(n1 * 256); e.D2 = b.take(n1 * 256); e.M1 = b.take(n1 * 256); e.UU = b.take(n1 * 256);
     const size_t ns = nsteps;
-    e.C1MS = b.take(n0 * 256); e.RMS = b.take(n0 * 256);
+    e.C1RMS = b.take(n0 * 512); e.AR0 = b.take(n0 * 512); e.AR1 = b.take(n1 * 512);
     e.tv = b.take(ns); e.temb_in = b.take(ns * in_ch); e.temb_a = b.take(ns * 1024); e.temb_b = b.take(ns * 1024); e.tproj = b.take(ns * 1536);
 }
 
@@ -700,26 +703,24 @@ int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
 // ---------------------------------------------------------------------------
 // estimator forward (decoder.py:363-443).  On entry X0 holds [x*m | mu*m | spk*m].
 // ---------------------------------------------------------------------------
-struct LevelBufs { float *A, *Bf, *R, *H, *LN, *QKV, *ATT, *FF; const float* rm; Geom g; };
+struct LevelBufs { float *A, *Bf, *R, *H, *LN, *QKV, *ATT, *FF; const float* rm; Geom g; float* AR; };
 
 int run_resnet(ev_handle* h, const ResnetW& w, const float* X, int ldx, const LevelBufs& L, const float* temb) {
     Epi e;
-    if (launch_conv(h, w.c1, X, ldx, L.A, 256, L.g, e)) return 1;
-    if (launch_gn(h, L.A, 256, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1)) return 1;
+    if (launch_conv(h, w.c1r, X, ldx, L.AR, 512, L.g, e)) return 1;                       // [block1 conv | res_conv]
+    if (launch_gn(h, L.AR, 512, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1)) return 1;
     if (launch_conv(h, w.c2, L.Bf, 256, L.A, 256, L.g, e)) return 1;
-    if (launch_conv(h, w.res, X, ldx, L.R, 256, L.g, e)) return 1;
-    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.R, 256, L.g, 256, 2);
+    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.AR + 256, 512, L.g, 256, 2);
 }
 
 // rn[0] with the time-invariant input share hoisted out of the Euler loop (see EstimatorW): X = X0 (x in columns [0, n_feats))
-int run_resnet0(ev_handle* h, const EstimatorW& W, const float* X, int ldx, const LevelBufs& L, const float* temb, const float* C1MS, const float* RMS) {
+int run_resnet0(ev_handle* h, const EstimatorW& W, const float* X, int ldx, const LevelBufs& L, const float* temb, const float* C1RMS) {
     const ResnetW& w = W.rn[0];
     Epi e;
-    { Epi e1; e1.R = C1MS; e1.ldr = 256; if (launch_conv(h, W.rn0_c1_x, X, ldx, L.A, 256, L.g, e1)) return 1; }
-    if (launch_gn(h, L.A, 256, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1)) return 1;
+    { Epi e1; e1.R = C1RMS; e1.ldr = 512; if (launch_conv(h, W.rn0_c1r_x, X, ldx, L.AR, 512, L.g, e1)) return 1; }
+    if (launch_gn(h, L.AR, 512, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1)) return 1;
     if (launch_conv(h, w.c2, L.Bf, 256, L.A, 256, L.g, e)) return 1;
-    { Epi e2; e2.R = RMS; e2.ldr = 256; if (launch_conv(h, W.rn0_res_x, X, ldx, L.R, 256, L.g, e2)) return 1; }
-    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.R, 256, L.g, 256, 2);
+    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.AR + 256, 512, L.g, 256, 2);
 }
 
 // BasicTransformerBlock (transformer.py:243-316) on L.H; result (masked) -> Z with row stride ldz
@@ -741,11 +742,11 @@ int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z,
 int run_estimator(ev_handle* h, EstBufs& b, int step, float dt, bool euler) {
     const EstimatorW& w = h->est;
     const int heads = h->dims.heads;
-    LevelBufs L0{b.A0, b.B0, b.R0, b.H0, b.LN0, b.QKV0, b.ATT0, b.FF0, b.rm0, b.g0};
-    LevelBufs L1{b.A1, b.B1, b.R1, b.H1, b.LN1, b.QKV1, b.ATT1, b.FF1, b.rm1, b.g1};
+    LevelBufs L0{b.A0, b.B0, b.R0, b.H0, b.LN0, b.QKV0, b.ATT0, b.FF0, b.rm0, b.g0, b.AR0};
+    LevelBufs L1{b.A1, b.B1, b.R1, b.H1, b.LN1, b.QKV1, b.ATT1, b.FF1, b.rm1, b.g1, b.AR1};
     const float* tp = b.tproj + (size_t)step * 1536;
     // down 0 @T
-    if (run_resnet0(h, w, b.X0, w.in_ch, L0, tp + 0 * 256, b.C1MS, b.RMS)) return 1;
+    if (run_resnet0(h, w, b.X0, w.in_ch, L0, tp + 0 * 256, b.C1RMS)) return 1;
     if (run_transformer(h, w.tr[0], L0, b.CAT1 + 256, 512, heads)) return 1;      // hidden 0
     {   // Downsample1D k3 s2 p1 over the pair view of CAT1[:, 256:512]
         Epi e; e.isplit_log2 = 8; e.isstride = 512; e.mask1 = 1; e.rowmask = b.rm1;
@@ -839,10 +840,8 @@ int prep_inputs(ev_handle* h, EstBufs& b, const float* d_x, const float* d_mu, c
     }
     HIPCHK(h, hipGetLastError());
     {   // time-invariant share of rn[0]: columns [n_feats, in_ch) of X0 = [mu*m | spk*m]
-        const int nf = h->dims.n_feats;
         Epi e;
-        if (launch_conv(h, w.rn0_c1_ms, b.X0 + nf, w.in_ch, b.C1MS, 256, b.g0, e)) return 1;
-        if (launch_conv(h, w.rn0_res_ms, b.X0 + nf, w.in_ch, b.RMS, 256, b.g0, e)) return 1;
+        if (launch_conv(h, w.rn0_c1r_ms, b.X0 + h->dims.n_feats, w.in_ch, b.C1RMS, 512, b.g0, e)) return 1;
     }
     return 0;
 }
@@ -1115,26 +1114,31 @@ int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* in
         const HostTensor *rw = T_(p + ".res_conv.weight"), *rb = T_(p + ".res_conv.bias");
         const HostTensor *tw = T_(p + ".mlp.1.weight"), *tb = T_(p + ".mlp.1.bias");
         if (!c1w || !c1b || !c2w || !c2b || !rw || !rb || !tw || !tb) return 1;
-        REQ(pack_conv(h, w.rn[i].c1, *c1w, c1b, 1));
+        // [block1 conv (k = 3) | res_conv (1x1 -> centre tap)] stacked along the output axis, input channels [c0, c1)
+        auto stack = [&](int c0, int c1, bool with_bias, ConvLayer& L) -> int {
+            const int Co = (int)c1w->shape[0], Ci = (int)c1w->shape[1], K = (int)c1w->shape[2], Cr = (int)rw->shape[0], n = c1 - c0;
+            std::vector<float> wt((size_t)(Co + Cr) * n * K, 0.f), bt((size_t)(Co + Cr), 0.f);
+            for (int co = 0; co < Co; ++co)
+                for (int ci = 0; ci < n; ++ci)
+                    for (int k = 0; k < K; ++k) wt[((size_t)co * n + ci) * K + k] = c1w->p[((size_t)co * Ci + c0 + ci) * K + k];
+            for (int co = 0; co < Cr; ++co)
+                for (int ci = 0; ci < n; ++ci) wt[((size_t)(Co + co) * n + ci) * K + K / 2] = rw->p[(size_t)co * Ci + c0 + ci];
+            for (int co = 0; co < Co; ++co) bt[co] = c1b->p[co];
+            for (int co = 0; co < Cr; ++co) bt[Co + co] = rb->p[co];
+            HostTensor wh, bh;
+            wh.p = wt.data(); wh.ndim = 3; wh.shape[0] = Co + Cr; wh.shape[1] = n; wh.shape[2] = K;
+            bh.p = bt.data(); bh.ndim = 1; bh.shape[0] = Co + Cr;
+            if (pack_conv(h, L, wh, with_bias ? &bh : nullptr, 1)) return 1;
+            L.macs_per_row = (double)Co * n * K + (double)Cr * n;          // the reference's arithmetic (zero taps are not work)
+            return 0;
+        };
+        if ((int)rw->shape[1] != (int)c1w->shape[1] || (int)c1w->shape[2] != 3) return fail(h, "resnet %d: unexpected conv shapes", i);
+        REQ(stack(0, (int)c1w->shape[1], true, w.rn[i].c1r));
         REQ(pack_conv(h, w.rn[i].c2, *c2w, c2b, 1));
-        REQ(pack_conv(h, w.rn[i].res, *rw, rb, 1));
         if (i == 0) {   // split along Cin at n_feats: [x | mu, spk]
-            auto slice = [&](const HostTensor& t, int c0, int c1, std::vector<float>& store, HostTensor& out) {
-                const int Co = (int)t.shape[0], Ci = (int)t.shape[1], K = t.ndim == 3 ? (int)t.shape[2] : 1;
-                store.resize((size_t)Co * (c1 - c0) * K);
-                for (int co = 0; co < Co; ++co)
-                    for (int ci = c0; ci < c1; ++ci)
-                        for (int k = 0; k < K; ++k) store[((size_t)co * (c1 - c0) + (ci - c0)) * K + k] = t.p[((size_t)co * Ci + ci) * K + k];
-                out = t; out.p = store.data(); out.shape[1] = c1 - c0;
-            };
             const int nf = h->dims.n_feats, cin = (int)c1w->shape[1];
-            std::vector<float> s1, s2, s3, s4;
-            HostTensor a, bms, c, dms;
-            slice(*c1w, 0, nf, s1, a); slice(*c1w, nf, cin, s2, bms); slice(*rw, 0, nf, s3, c); slice(*rw, nf, cin, s4, dms);
-            REQ(pack_conv(h, w.rn0_c1_x, a, nullptr, 1));
-            REQ(pack_conv(h, w.rn0_c1_ms, bms, c1b, 1));
-            REQ(pack_conv(h, w.rn0_res_x, c, nullptr, 1));
-            REQ(pack_conv(h, w.rn0_res_ms, dms, rb, 1));
+            REQ(stack(0, nf, false, w.rn0_c1r_x));
+            REQ(stack(nf, cin, true, w.rn0_c1r_ms));
         }
         REQ(upload_vec(h, m, p + ".block1.block.1.weight", &w.rn[i].g1));
         REQ(upload_vec(h, m, p + ".block1.block.1.bias", &w.rn[i].b1));
