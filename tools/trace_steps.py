@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Per-pass totals of the conv kernels (conv_gemm_kernel + resblock_pair_kernel) from a rocprofv3 --kernel-trace CSV of
-`bench.py`.  Every pass over the path issues the same number of conv launches (539 at config 2).  The LAST four passes of a
+`bench.py`.  Every pass over the path issues the same number of conv launches (480 at config 2).  The LAST four passes of a
 default run are un-overlapped, in this order: the HIP-event roofline pass, the batch-latency pass, the PCIe-inclusive pass and
 the B=8 parity pass; the warm-up and timed passes before them are pipelined on two streams (their kernels overlap, so their
 durations are not comparable with the roofline pass and are reported only as a group).
-    python tools/trace_steps.py <rocprof output dir> [launches per pass, default 539]"""
+    python tools/trace_steps.py <rocprof output dir> [conv launches per pass: 480 at config 2]"""
 import csv, glob, sys
 kt = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
-n = int(sys.argv[2]) if len(sys.argv) > 2 else 539
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 480
 rows = sorted(csv.DictReader(open(kt)), key=lambda r: int(r["Dispatch_Id"]))
 conv = [r for r in rows if "conv_gemm" in r["Kernel_Name"] or "resblock_pair" in r["Kernel_Name"]]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
