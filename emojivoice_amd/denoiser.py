@@ -35,6 +35,7 @@ class Denoiser:
         shape = audio.shape
         self.vocoder._sync_engine()
         out = self.vocoder.engine.denoise(audio.reshape(-1, shape[-1]), self.bias_spec.reshape(-1), strength)
-        return out.reshape(shape)        # (L,) -> (L,), (B, L) -> (B, L) like torch.istft on the reference's spectra
+        # the reference's (1, 513, 1) bias spectrum broadcasts a 1-D input's spectrum to a batch of one: (L,) -> (1, L), (B, L) -> (B, L)
+        return out.reshape((1, shape[-1])) if audio.dim() == 1 else out.reshape(shape)
 
     __call__ = forward

@@ -155,6 +155,7 @@ def test_denoiser_vs_golden(golden, vocoder):
     d = den(audio, strength=0.00025)
     assert tuple(d.shape) == golden["g7_denoised"].shape        # length stays 256*T, (B, L)
     assert _linf(d, golden["g7_denoised"]) <= 1e-4
+    assert tuple(den(audio[0], strength=0.00025).shape) == (1, audio.shape[-1])     # 1-D input comes back as a batch of one (bias broadcast)
 
 
 def test_cli_writes_pcm24_wav(tmp_path):
