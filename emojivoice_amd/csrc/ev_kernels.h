@@ -320,7 +320,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
                 if (ok && p.accum) ra[set][q] = ev_bload4(rY, ao, 0);
                 ao += ystep;
             }
-            tt += RPP; if (tt >= p.S - p.P) tt -= p.S;
+            tt += RPP; while (tt >= p.S - p.P) tt -= p.S;   // (more than one wrap when an utterance is shorter than a pass: S < RPP)
             ro += rstep;
         }
     };
@@ -364,7 +364,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
                 }
             }
             if (ok) ev_bstore4(rY, yoff, v);
-            t += RPP; if (t >= p.S - p.P) t -= p.S;
+            t += RPP; while (t >= p.S - p.P) t -= p.S;
             yoff += ystep;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next slab overwrites Es

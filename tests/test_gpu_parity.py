@@ -175,15 +175,16 @@ def test_cli_writes_pcm24_wav(tmp_path):
         assert w.getnframes() == 256 * mel.shape[1]
 
 
-@pytest.mark.parametrize("B,Tp,lens,steps", [(1, 4, [3], 2), (2, 8, [8, 1], 3), (1, 1032, [1030], 2)])
+@pytest.mark.parametrize("B,Tp,lens,steps", [(1, 4, [3], 2), (2, 8, [8, 1], 3), (1, 1032, [1030], 2), (7, 4, [4, 1, 3, 4, 2, 4, 3], 2)])
 def test_cfm_edge_shapes(model, matcha_sd, B, Tp, lens, steps):
-    """Smallest legal Tp (4), a 1-frame utterance beside a full one, and a 12-s utterance (33 key tiles in attention)."""
+    """Smallest legal Tp (4), a 1-frame utterance beside a full one, a 12-s utterance (33 key tiles in attention), and a batch
+    of utterances shorter than one epilogue pass (S < 8 rows: several wraps of the row bookkeeping)."""
     g = torch.Generator().manual_seed(Tp + 7)
     mu = torch.randn(B, 80, Tp, generator=g)
     z = torch.randn(B, 80, Tp, generator=g)
     lengths = torch.tensor(lens)
     mask = O.sequence_mask(lengths, Tp).unsqueeze(1).float()
-    spk = matcha_sd["spk_emb.weight"][torch.tensor([17, 0][:B])]
+    spk = matcha_sd["spk_emb.weight"][torch.tensor([17, 0, 5, 9, 33, 71, 108][:B])]
     ref = O.cfm_decode(matcha_sd, mu * mask, mask, steps, 1.0, spk, z=z)
     dec, _ = model.decode((mu * mask).cuda(), lengths.cuda(), steps, 1.0, spk.cuda(), z=z.cuda())
     assert _linf(dec, ref) <= MEL_GATE / 2
@@ -302,3 +303,16 @@ def test_denoiser_vs_oracle_batched(vocoder):
         ref = O.denoiser(audio, bias[None, :, None], strength=0.01)
         got = eng.denoise(audio.cuda(), bias.cuda(), 0.01)
         assert _linf(got, ref) <= 2e-5
+
+
+def test_text_encoder_short_utterances(model, matcha_sd):
+    """Utterances shorter than one epilogue pass (S = Tx + 4 < 8 rows): several wraps of the row bookkeeping per pass."""
+    g = torch.Generator().manual_seed(9)
+    for B, Tx in ((6, 3), (10, 3), (9, 1), (5, 2)):
+        ids = torch.randint(0, 178, (B, Tx), generator=g)
+        lens = torch.randint(1, Tx + 1, (B,), generator=g)
+        sid = torch.randint(0, 109, (B,), generator=g)
+        spk = torch.nn.functional.embedding(sid, matcha_sd["spk_emb.weight"])
+        mu, logw = model.engine.text_encoder(ids.cuda(), lens.cuda(), spk.cuda())
+        rmu, rlogw, _ = O.text_encoder(matcha_sd, ids, lens, spk)
+        assert _linf(mu, rmu) <= 1e-4 and _linf(logw, rlogw) <= 1e-4, (B, Tx)
