@@ -81,15 +81,24 @@ def cpu_baseline(sd, voc_sd, mu, z0, spk, n_ode):
     sample_b, _, T = mu.shape
     log(f"[bench] cpu baseline: oracle on {cores} host threads, B={sample_b} ...")
     mask = torch.ones(sample_b, 1, T)
-    t0 = time.perf_counter()
-    with torch.inference_mode():
-        dec = O.solve_euler(sd, z0, mu, mask, n_ode, spk)
-        mel = O.denormalize(dec, sd["mel_mean"], sd["mel_std"])
-        wav = O.hifigan_forward(voc_sd, mel, W.HIFIGAN_V1)
-    dt = time.perf_counter() - t0
+
+    def run(n):
+        with torch.inference_mode():
+            dec = O.solve_euler(sd, z0[:n], mu[:n], mask[:n], n_ode, spk[:n] if spk is not None else None)
+            mel = O.denormalize(dec, sd["mel_mean"], sd["mel_std"])
+            return mel, O.hifigan_forward(voc_sd, mel, W.HIFIGAN_V1)
+
+    run(1)                                   # warm-up (thread pool, oneDNN primitives): one utterance, ~1-2 s
+    times = []
+    for _ in range(2):                       # two timed calls on the full sample, the faster one is reported
+        t0 = time.perf_counter()
+        mel, wav = run(sample_b)
+        times.append(time.perf_counter() - t0)
+    dt = min(times)
     audio_s = sample_b * T * HOP / SR
     return {"value": round(audio_s / dt, 3), "unit": "audio_s/s", "cores": cores, "kind": "port",
-            "sample": f"first {sample_b} utterances of the batch (T={T} frames), {n_ode} Euler steps + HiFi-GAN, 1 call, {dt:.1f} s wall"}, mel, wav
+            "sample": f"first {sample_b} utterances of the batch (T={T} frames), {n_ode} Euler steps + HiFi-GAN; 1-utterance warm-up, "
+                      f"best of 2 calls ({times[0]:.1f} / {times[1]:.1f} s wall)"}, mel, wav
 
 
 def main():
