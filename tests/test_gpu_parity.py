@@ -316,3 +316,8 @@ def test_text_encoder_short_utterances(model, matcha_sd):
         mu, logw = model.engine.text_encoder(ids.cuda(), lens.cuda(), spk.cuda())
         rmu, rlogw, _ = O.text_encoder(matcha_sd, ids, lens, spk)
         assert _linf(mu, rmu) <= 1e-4 and _linf(logw, rlogw) <= 1e-4, (B, Tx)
+
+
+def test_warmup_calls(model, vocoder):
+    model.warmup()
+    vocoder.warmup()
