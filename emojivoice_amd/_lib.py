@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 EXPORTS = [
     "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder", "ev_load_text_encoder", "ev_text_encoder",
-    "ev_stft_magnitude", "ev_denoise",
+    "ev_stft_magnitude", "ev_denoise", "ev_align",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention",
 ]
@@ -83,6 +83,7 @@ def load_library() -> C.CDLL:
     lib.ev_hifigan.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.ev_text_encoder.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
     lib.ev_stft_magnitude.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.ev_align.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.ev_denoise.argtypes = [vp, vp, i32, i32, vp, f32, vp, vp]
     lib.ev_profile_enable.argtypes = [vp, i32]
     lib.ev_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
@@ -158,6 +159,20 @@ class Engine:
 
     def load_vocoder(self, tensors: Dict[str, torch.Tensor]):
         self._load(self.lib.ev_load_vocoder, tensors, "ev_load_vocoder")
+
+    def align(self, w_ceil, mu_x, x_lengths, y_lengths, Tp: int, want_attn: bool = True):
+        """generate_path + mu_y = attn^T mu_x (utils/model.py:29-41, matcha_tts.py:131-135).  Returns (mu_y (B,80,Tp), attn (B,1,Tx,Tp))."""
+        w = self._f32(w_ceil).reshape(w_ceil.shape[0], -1)
+        mu_x = self._f32(mu_x)
+        B, F, Tx = mu_x.shape
+        assert F == 80 and w.shape == (B, Tx)
+        xl = x_lengths.to(mu_x.device, torch.int32).contiguous()
+        yl = y_lengths.to(mu_x.device, torch.int64).contiguous()
+        mu_y = torch.empty((B, F, Tp), dtype=torch.float32, device=mu_x.device)
+        attn = torch.empty((B, 1, Tx, Tp), dtype=torch.float32, device=mu_x.device) if want_attn else None
+        self._check(self.lib.ev_align(self.h, w.data_ptr(), mu_x.data_ptr(), xl.data_ptr(), yl.data_ptr(), B, Tx, int(Tp), mu_y.data_ptr(),
+                                      attn.data_ptr() if attn is not None else None, _stream_ptr()), "ev_align")
+        return mu_y, attn
 
     def stft_magnitude(self, audio):
         """|STFT| (B, 513, L/256 + 1) of (B, L) audio with the denoiser's STFT (denoiser.py:36-56)."""

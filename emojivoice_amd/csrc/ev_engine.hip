@@ -1392,6 +1392,17 @@ int ev_estimator(ev_handle* h, const float* d_x, const float* d_mu, const int32_
     return 0;
 }
 
+int ev_align(ev_handle* h, const float* d_wceil, const float* d_mu_x, const int32_t* d_xlen, const int64_t* d_ylen, int B, int Tx, int Tp,
+             float* d_mu_y, float* d_attn, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (B <= 0 || Tx <= 0 || Tp <= 0 || Tx > 8192 || !d_wceil || !d_mu_x || !d_xlen || !d_ylen || !d_mu_y) return fail(h, "bad arguments B=%d Tx=%d Tp=%d", B, Tx, Tp);
+    hipLaunchKernelGGL(enc_align_kernel, dim3(B), dim3(256), (size_t)Tx * sizeof(float), (hipStream_t)stream, d_wceil, d_mu_x, d_xlen, d_ylen, d_mu_y, d_attn,
+                       h->dims.n_feats, Tx, Tp);
+    HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
 int ev_stft_magnitude(ev_handle* h, const float* d_audio, int B, int L, float* d_mag, void* stream) {
     if (!h) return 1;
     HIPCHK(h, hipSetDevice(h->device));

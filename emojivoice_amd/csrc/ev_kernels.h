@@ -1482,6 +1482,34 @@ __global__ __launch_bounds__(256) void enc_attention_kernel(const float* QKV, in
     if (act) *(float2*)(O + (row0 + tq) * ldo + dq) = o;
 }
 
+// Hard monotonic alignment + expansion (utils/model.py:29-41 generate_path, matcha_tts.py:131-135): one workgroup per
+// utterance.  cum = cumsum(w_ceil) is accumulated sequentially (in double, rounded per prefix: torch's CPU cumsum); path[i][ty] = [ty < cum[i]] -
+// [ty < cum[i-1]] (float compare against arange, as sequence_mask does), masked by x_mask[i] * y_mask[ty]; mu_y[:, ty] =
+// sum_i path[i][ty] * mu_x[:, i] — at most one non-zero term per output frame, so the matmul of the reference is a gather.
+__global__ __launch_bounds__(256) void enc_align_kernel(const float* wceil, const float* mu_x, const int32_t* xlen, const int64_t* ylen,
+                                                        float* mu_y, float* attn, int C, int Tx, int Tp) {
+    extern __shared__ float cum[];                  // [Tx]
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        double acc = 0.0;                          // torch's CPU cumsum accumulates float32 in double and rounds each prefix
+        for (int i = 0; i < Tx; ++i) { acc += (double)wceil[(size_t)b * Tx + i]; cum[i] = (float)acc; }
+    }
+    __syncthreads();
+    const int lx = xlen[b];
+    const long ly = ylen[b];
+    for (int ty = tid; ty < Tp; ty += blockDim.x) {
+        const float fy = (float)ty;
+        int src = -1;                                // the token whose [cum[i-1], cum[i]) interval holds ty
+        if (ty < ly) {
+            int lo = 0, hi = Tx;                     // first i with fy < cum[i]
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (fy < cum[mid]) hi = mid; else lo = mid + 1; }
+            if (lo < Tx && lo < lx) src = lo;
+        }
+        if (attn) for (int i = 0; i < Tx; ++i) attn[((size_t)b * Tx + i) * Tp + ty] = (i == src) ? 1.f : 0.f;
+        for (int c = 0; c < C; ++c) mu_y[((size_t)b * C + c) * Tp + ty] = src >= 0 ? mu_x[((size_t)b * C + c) * Tx + src] : 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Denoiser (hifigan/denoiser.py) support kernels.  The STFT / inverse STFT (n_fft 1024, hop 256, periodic Hann window,
 // centred with reflect padding — torch.stft / torch.istft defaults as the reference calls them) are two convolutions on

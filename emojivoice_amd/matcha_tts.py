@@ -138,9 +138,12 @@ class MatchaTTS:
         y_max_length = int(y_lengths.max())
         y_max_length_ = fix_len_compatibility(y_max_length)
         y_mask = sequence_mask(y_lengths, y_max_length_).unsqueeze(1).to(x_mask.dtype)
-        attn_mask = x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)
-        attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
-        mu_y = torch.matmul(attn.squeeze(1).transpose(1, 2), mu_x.transpose(1, 2)).transpose(1, 2)
+        if self.encoder_stage == "host":
+            attn_mask = x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)
+            attn = generate_path(w_ceil.squeeze(1), attn_mask.squeeze(1)).unsqueeze(1)
+            mu_y = torch.matmul(attn.squeeze(1).transpose(1, 2), mu_x.transpose(1, 2)).transpose(1, 2)
+        else:
+            mu_y, attn = self.engine.align(w_ceil, mu_x, x_lengths, y_lengths, y_max_length_)
         encoder_outputs = mu_y[:, :, :y_max_length]
 
         dec, mel = self.decode(mu_y, y_lengths, n_timesteps, temperature, spk, z=z)

@@ -103,6 +103,13 @@ int ev_estimator(ev_handle *h, const float *d_x, const float *d_mu, const int32_
 int ev_text_encoder(ev_handle *h, const int64_t *d_ids, const int32_t *d_lengths, const float *d_spk, int B, int Tx,
                     float *d_mu, float *d_logw, void *stream);
 
+/* Hard monotonic alignment and expansion (utils/model.py:29-41 generate_path; matcha_tts.py:131-135):
+ *   d_wceil (B, Tx) f32   ceil(exp(logw) * x_mask) * length_scale        d_mu_x (B, 80, Tx)
+ *   d_xlen (B) int32, d_ylen (B) int64 (= clamp_min(sum(w_ceil), 1).long(), computed by the caller: its maximum fixes Tp)
+ *   d_mu_y (B, 80, Tp) = attn^T mu_x;   d_attn (B, Tx, Tp) 0/1 path, may be NULL */
+int ev_align(ev_handle *h, const float *d_wceil, const float *d_mu_x, const int32_t *d_xlen, const int64_t *d_ylen,
+             int B, int Tx, int Tp, float *d_mu_y, float *d_attn, void *stream);
+
 /* HiFi-GAN V1 generator: d_mel (B, 80, T) -> d_wav (B, 256*T), tanh output, no clamp/denoiser. */
 int ev_hifigan(ev_handle *h, const float *d_mel, int B, int T, float *d_wav, void *stream);
 

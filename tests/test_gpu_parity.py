@@ -321,3 +321,25 @@ def test_text_encoder_short_utterances(model, matcha_sd):
 def test_warmup_calls(model, vocoder):
     model.warmup()
     vocoder.warmup()
+
+
+def test_align_vs_oracle(model):
+    """ev_align (generate_path + mu_y = attn^T mu_x) vs the oracle's generate_path / matmul, integer and fractional
+    length scales, ragged token lengths, incl. an all-zero-duration utterance (y_length clamps to 1)."""
+    g = torch.Generator().manual_seed(13)
+    for scale in (1.0, 0.8, 1.37):
+        B, Tx = 5, 23
+        xl = torch.tensor([23, 1, 17, 9, 23])
+        x_mask = O.sequence_mask(xl, Tx).unsqueeze(1).float()
+        logw = torch.randn(B, 1, Tx, generator=g) * 0.7 + 0.3
+        logw[3] = -30.0                                            # exp -> 0: ceil(0) = 0 for every token
+        w_ceil = torch.ceil(torch.exp(logw) * x_mask) * scale
+        yl = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+        Tp = O.fix_len_compatibility(int(yl.max()))
+        y_mask = O.sequence_mask(yl, Tp).unsqueeze(1).float()
+        ref_attn = O.generate_path(w_ceil.squeeze(1), (x_mask.unsqueeze(-1) * y_mask.unsqueeze(2)).squeeze(1))
+        mu_x = torch.randn(B, 80, Tx, generator=g)
+        ref_mu_y = torch.matmul(ref_attn.transpose(1, 2), mu_x.transpose(1, 2)).transpose(1, 2)
+        mu_y, attn = model.engine.align(w_ceil.cuda(), mu_x.cuda(), xl.cuda(), yl.cuda(), Tp)
+        assert torch.equal(attn.squeeze(1).cpu(), ref_attn), scale
+        assert torch.equal(mu_y.cpu(), ref_mu_y), scale
