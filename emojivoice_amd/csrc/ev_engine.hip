@@ -419,6 +419,9 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
             if (t < best - 1e-9) { best = t; cfg = c.cfg; }
         }
     }
+    // stacked layers (a 3-tap conv over a 1x1 conv: half of the M tiles carry one tap) in about one round of workgroups: the
+    // 64 x 64 tile balances the heavy and the light tiles best (measured 3.6 -> 3.1 ms on the T/2-level resnets)
+    if (L.sparse_taps && L.Cout > 32 && (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64) <= 256L * 5 * 2) cfg = 6;
     // launches far below one round of workgroups are a latency chain per workgroup: use the build that prefetches the
     // next chunk's X tile through registers (measured 7-10 % on batch-1 decodes, nothing on full grids)
     if (cfg == 6 && (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64) <= 320) cfg = 8;
