@@ -20,7 +20,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 EXPORTS = [
     "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder", "ev_load_text_encoder", "ev_text_encoder",
-    "ev_stft_magnitude", "ev_denoise", "ev_align",
+    "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention",
 ]
@@ -82,6 +82,8 @@ def load_library() -> C.CDLL:
     lib.ev_estimator.argtypes = [vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]
     lib.ev_hifigan.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.ev_text_encoder.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.ev_text_encoder_status.argtypes = [vp, vp]
+    lib.ev_dbg_conv_bench.argtypes = [vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float)]
     lib.ev_stft_magnitude.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.ev_align.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.ev_denoise.argtypes = [vp, vp, i32, i32, vp, f32, vp, vp]
@@ -210,6 +212,12 @@ class Engine:
         self._check(self.lib.ev_text_encoder(self.h, ids.data_ptr(), lengths.data_ptr(), spk_p, B, Tx, mu.data_ptr(), logw.data_ptr(), _stream_ptr()),
                     "ev_text_encoder")
         return mu, logw
+
+    def text_encoder_status(self):
+        """Raises IndexError if a token id outside [0, n_vocab) was seen since the last check (the reference's nn.Embedding
+        raises at the lookup, text_encoder.py:395); waits for the current stream."""
+        if self.lib.ev_text_encoder_status(self.h, _stream_ptr()) != 0:
+            raise IndexError(self.lib.ev_last_error(self.h).decode())
 
     # ---- hot calls -----------------------------------------------------------
     @staticmethod

@@ -1,7 +1,8 @@
 """Counterpart of the ``matcha-tts`` CLI (reference Matcha-TTS/matcha/cli.py:160-250) for the MI355X path
 (SURVEY §8 f-2).  The phonemiser front end (espeak-ng) is out of scope, so utterances are given as phoneme-id
 sequences (``--ids "12 0 45 ..."`` or ``--file`` with one sequence per line, optional ``|speaker`` suffix like
-cli.py:332-336); everything after that point mirrors the reference: validate_args (:138-158), load_matcha / load_vocoder
+cli.py:332-336) or as pre-phonemised IPA text (``--phonemes "həlˈoʊ wˈɜːld"``, mapped through the reference's symbol table,
+emojivoice_amd/text.py); everything after that point mirrors the reference: validate_args (:138-158), load_matcha / load_vocoder
 (:84-118), unbatched / batched synthesis (:277-317, :389-425), ``to_waveform`` (:121-126), PCM_24 wav files (:134).
 
     python -m emojivoice_amd.cli --checkpoint_path model.ckpt --vocoder_path g_02500000 --ids "0 23 0 51 0" --spk 12
@@ -21,11 +22,7 @@ import numpy as np
 import torch
 
 
-def intersperse(lst, item):
-    """utils/utils.py:131-135."""
-    result = [item] * (len(lst) * 2 + 1)
-    result[1::2] = lst
-    return result
+from .text import cleaned_text_to_sequence, intersperse  # noqa: E402  (utils/utils.py:131-135, text/__init__.py:27-35)
 
 
 def write_wav_pcm24(path, wav: np.ndarray, sr: int = 22050):
@@ -39,7 +36,7 @@ def write_wav_pcm24(path, wav: np.ndarray, sr: int = 22050):
 
 
 def validate_args(args):
-    assert args.ids or args.file, "Either --ids or --file must be provided"
+    assert args.ids or args.file or args.phonemes, "One of --ids, --phonemes or --file must be provided"
     assert args.temperature >= 0, "Sampling temperature cannot be negative"
     assert args.steps > 0, "Number of ODE steps must be greater than 0"
     if args.speaking_rate is None:
@@ -79,6 +76,9 @@ def to_waveform(mel, vocoder, denoiser=None, strength=0.00025):
 
 
 def parse_lines(args):
+    if args.phonemes is not None:
+        # pre-phonemised (IPA) text -> ids exactly as process_text does after its cleaner (cli.py:52-56): always with blanks
+        return [(intersperse(cleaned_text_to_sequence(args.phonemes), 0), None)]
     lines = [args.ids] if args.ids else open(args.file, encoding="utf-8").read().splitlines()
     out = []
     for ln in lines:
@@ -87,11 +87,14 @@ def parse_lines(args):
             continue
         spk = None
         if "|" in ln:
-            ln, s = ln.split("|", 1)
+            ln, s = ln.rsplit("|", 1)
             spk = int(s)
-        ids = [int(t) for t in ln.split()]
-        if args.add_blank:
-            ids = intersperse(ids, 0)
+        if args.file_phonemes:
+            ids = intersperse(cleaned_text_to_sequence(ln), 0)
+        else:
+            ids = [int(t) for t in ln.split()]
+            if args.add_blank:
+                ids = intersperse(ids, 0)
         out.append((ids, spk))
     return out
 
@@ -103,7 +106,10 @@ def cli(argv=None):
     p.add_argument("--vocoder_path", type=str, default=None, help="HiFi-GAN generator checkpoint (dict with 'generator')")
     p.add_argument("--synthetic", action="store_true", help="random-init weights (no checkpoint is available offline)")
     p.add_argument("--ids", type=str, default=None, help="phoneme ids of one utterance, space separated")
+    p.add_argument("--phonemes", type=str, default=None, help="one pre-phonemised (IPA) utterance, e.g. the output of english_cleaners2; "
+                   "mapped through the 198-symbol table and interspersed with blanks like the reference front end")
     p.add_argument("--file", type=str, default=None, help="one id sequence per line, optional '|speaker'")
+    p.add_argument("--file_phonemes", action="store_true", help="lines of --file are IPA strings, not ids")
     p.add_argument("--add_blank", action="store_true", help="intersperse ids with 0 like the reference front end")
     p.add_argument("--emoji-text", type=str, default=None, help="LLM-style text; its first mapped emoji selects the speaker (feel_me.py)")
     p.add_argument("--spk", type=int, default=None)

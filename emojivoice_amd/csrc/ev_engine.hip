@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -103,8 +104,11 @@ struct ev_handle {
     VocoderW voc;
     TextEncW enc;
     DenoiserW dn;
-    char* dn_ws = nullptr; size_t dn_ws_bytes = 0;
-    char* enc_ws = nullptr; size_t enc_ws_bytes = 0;   // the text encoder's own (small) workspace
+    // small per-stage scratch arenas (denoiser, text encoder): grown on demand, ordered against their last user's stream
+    struct Scratch { char* p = nullptr; size_t bytes = 0; hipStream_t last = nullptr; bool last_valid = false; };
+    Scratch dn_ws, enc_ws;
+    int max_steps = 64;         // Euler steps the time-grid buffers of the workspace are planned for (grows on demand)
+    int* bad_ids_host = nullptr; int* bad_ids_dev = nullptr;   // mapped host word: count of out-of-range token ids seen by ev_text_encoder
     // workspace
     char* ws = nullptr; size_t ws_bytes = 0; size_t ws_used = 0;
     int ws_B = -1, ws_Tp = -1, ws_Tv = -1;
@@ -142,6 +146,22 @@ int dev_upload(ev_handle* h, const std::vector<T>& v, T** out) {
 }
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// Make a scratch arena at least `need` bytes for a call on h->stream.  No device-wide synchronisation: only the stream of
+// the arena's previous user (if it differs) and, when the arena must be replaced, the current stream are waited for, so a
+// second handle working on another stream (BatchPipeline) is never stalled.
+int scratch_acquire(ev_handle* h, ev_handle::Scratch& s, size_t need) {
+    if (s.last_valid && s.last != h->stream) HIPCHK(h, hipStreamSynchronize(s.last));
+    if (need > s.bytes) {
+        if (s.last_valid) HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (s.p) HIPCHK(h, hipFree(s.p));
+        s.p = nullptr; s.bytes = 0;
+        HIPCHK(h, hipMalloc((void**)&s.p, need));
+        s.bytes = need;
+    }
+    s.last = h->stream; s.last_valid = true;
+    return 0;
+}
 
 // finalize a layer whose packed host weights Wh [ntaps][Mpad][Kpad] and bias are given
 int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const std::vector<float>* bias) {
@@ -310,11 +330,28 @@ int upload_vec(ev_handle* h, const TensorMap& m, const std::string& k, float** o
 // ---------------------------------------------------------------------------
 // launching
 // ---------------------------------------------------------------------------
-static int g_xrows_halo = EV_HALO;   // halo rows of the layer being launched (LDS is sized for BN + halo, not BN + EV_HALO)
-static int g_dbg_wgs_per_cu = 0;   // tools/conv_bench.py: cap workgroups per CU by over-allocating LDS (0 = off)
+// Per-launch host-side state (no file-scope mutable state: different handles may be driven from different host threads)
+struct LaunchOpts {
+    int halo = EV_HALO;      // halo rows of the layer being launched (LDS is sized for BN + halo, not BN + EV_HALO)
+    int kb = 1;              // k-chunks per stage (see conv_gemm_kernel: KB)
+    int wgs_per_cu = 0;      // tools/conv_bench.py: cap workgroups per CU by over-allocating LDS (0 = off)
+    int device = 0;
+};
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is sticky per (function, device): issue it only when a launch needs more
+// than any earlier launch of that instantiation asked for (it costs host time on the ~640-launch batch-1 chain).
+template <typename K>
+inline void ensure_dyn_smem(K kernel, size_t smem, int device) {
+    static std::atomic<int> granted[16];
+    const int d = device & 15;
+    if (smem <= 65536 || (int)smem <= granted[d].load(std::memory_order_relaxed)) return;
+    hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    int cur = granted[d].load(std::memory_order_relaxed);
+    while (cur < (int)smem && !granted[d].compare_exchange_weak(cur, (int)smem, std::memory_order_relaxed)) {}
+}
 
 template <int BM, int BN, int WM, int WN, bool PF, bool FULL, int LEAN, int KB = 1>
-void launch_cfg2(const ConvParams& p, hipStream_t st);
+void launch_cfg2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo);
 
 // Dispatch on the epilogue flavour:
 //   lean    : y = act(acc + bias) [+ R], act in {none, lrelu, SnakeBeta}, plain row-major Y/R, Cout % 4 == 0
@@ -329,50 +366,49 @@ inline bool lean_ok(const ConvParams& p) {
            !p.Y2 && p.osplit_log2 >= 31 && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (!p.R || (p.ldr & 3) == 0) &&
            (!p.bias || ((size_t)p.bias & 15) == 0) && !(p.dbg & 4);
 }
-static int g_kb = 1;   // k-chunks per stage for the launch being issued (see conv_gemm_kernel: KB)
 template <int BM, int BN, int WM, int WN, bool PF = false>
-void launch_cfg(const ConvParams& p, hipStream_t st) {
+void launch_cfg(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
-    const bool kb2 = !PF && g_kb == 2;
+    const bool kb2 = !PF && lo.kb == 2;
     if (!no_lean && lean_ok(p)) {
-        if (p.act == ACT_SNAKE) { if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 2, 2>(p, st); else launch_cfg2<BM, BN, WM, WN, PF, false, 2>(p, st); }
-        else if (lean_acc(p)) { if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 3, 2>(p, st); else launch_cfg2<BM, BN, WM, WN, PF, false, 3>(p, st); }
-        else { if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 1, 2>(p, st); else launch_cfg2<BM, BN, WM, WN, PF, false, 1>(p, st); }
+        if (p.act == ACT_SNAKE) { if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 2, 2>(p, st, lo); else launch_cfg2<BM, BN, WM, WN, PF, false, 2>(p, st, lo); }
+        else if (lean_acc(p)) { if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 3, 2>(p, st, lo); else launch_cfg2<BM, BN, WM, WN, PF, false, 3>(p, st, lo); }
+        else { if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 1, 2>(p, st, lo); else launch_cfg2<BM, BN, WM, WN, PF, false, 1>(p, st, lo); }
     } else if (p.act == ACT_NONE || p.act == ACT_LRELU) {
-        if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 0, 2>(p, st); else launch_cfg2<BM, BN, WM, WN, PF, false, 0>(p, st);
-    } else launch_cfg2<BM, BN, WM, WN, PF, true, 0>(p, st);
+        if (kb2) launch_cfg2<BM, BN, WM, WN, false, false, 0, 2>(p, st, lo); else launch_cfg2<BM, BN, WM, WN, PF, false, 0>(p, st, lo);
+    } else launch_cfg2<BM, BN, WM, WN, PF, true, 0>(p, st, lo);
 }
 
 template <int BM, int BN, int WM, int WN, bool PF, bool FULL, int LEAN, int KB>
-void launch_cfg2(const ConvParams& p, hipStream_t st) {
+void launch_cfg2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     // LDS holds the X tile during the K loop and, afterwards, one transposed 32-frame slab per wave for the epilogue
-    const size_t xs = (size_t)(BN + ((g_xrows_halo + 7) & ~7)) * (32 * KB + 4);
+    const size_t xs = (size_t)(BN + ((lo.halo + 7) & ~7)) * (32 * KB + 4);
     constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4);
     size_t smem = (xs > es ? xs : es) * sizeof(float);
-    if (g_dbg_wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / g_dbg_wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; }
-    if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (lo.wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / lo.wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; }
+    ensure_dyn_smem(conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>, smem, lo.device);
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
 // small-launch build (conv_gemm_sk_kernel): 64 x 64 tiles, 16 waves, K split four ways inside the workgroup
 template <bool FULL, int LEAN>
-void launch_sk2(const ConvParams& p, hipStream_t st) {
+void launch_sk2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     constexpr int KS = 4;
     const int nchunks = p.Kpad / EV_BK, kbs = nchunks < 8 ? nchunks : 8;
-    const size_t xs = 2 * EV_MAX_TAPS + (size_t)(64 + ((g_xrows_halo + 7) & ~7)) * (32 * kbs + 4);
+    const size_t xs = 2 * EV_MAX_TAPS + (size_t)(64 + ((lo.halo + 7) & ~7)) * (32 * kbs + 4);
     const size_t red = (size_t)(KS - 1) * 4 * 16 * 64, es = (size_t)4 * 32 * 36;
     size_t smem = std::max(xs, std::max(red, es)) * sizeof(float);
-    if (smem > 65536) hipFuncSetAttribute((const void*)conv_gemm_sk_kernel<KS, FULL, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    ensure_dyn_smem(conv_gemm_sk_kernel<KS, FULL, LEAN>, smem, lo.device);
     hipLaunchKernelGGL((conv_gemm_sk_kernel<KS, FULL, LEAN>), dim3(p.mtiles * p.ntiles), dim3(256 * KS), smem, st, p);
 }
-void launch_sk(const ConvParams& p, hipStream_t st) {
+void launch_sk(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
     if (!no_lean && lean_ok(p)) {
-        if (p.act == ACT_SNAKE) launch_sk2<false, 2>(p, st);
-        else if (lean_acc(p)) launch_sk2<false, 3>(p, st);
-        else launch_sk2<false, 1>(p, st);
-    } else if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_sk2<false, 0>(p, st);
-    else launch_sk2<true, 0>(p, st);
+        if (p.act == ACT_SNAKE) launch_sk2<false, 2>(p, st, lo);
+        else if (lean_acc(p)) launch_sk2<false, 3>(p, st, lo);
+        else launch_sk2<false, 1>(p, st, lo);
+    } else if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_sk2<false, 0>(p, st, lo);
+    else launch_sk2<true, 0>(p, st, lo);
 }
 
 int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {
@@ -440,14 +476,14 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         static const char* env = getenv("EV_FORCE_CFG");
         if (env && *env) cfg = atoi(env);
     }
-    g_dbg_wgs_per_cu = 0;
-    g_kb = 1;
+    LaunchOpts lo;
+    lo.device = h->device;
     {   // A/B override: EV_KB=<1|2> forces the k-chunks per stage of every conv launch
         static const char* kenv = getenv("EV_KB");
-        if (kenv && *kenv) g_kb = atoi(kenv) == 2 ? 2 : 1;
+        if (kenv && *kenv) lo.kb = atoi(kenv) == 2 ? 2 : 1;
     }
-    if (e.force_cfg >= 0) { cfg = e.force_cfg % 100; g_dbg_wgs_per_cu = (e.force_cfg / 100) % 10; g_kb = e.force_cfg >= 1000 ? 2 : 1; }
-    g_xrows_halo = L.halo_lo + L.halo_hi;
+    if (e.force_cfg >= 0) { cfg = e.force_cfg % 100; lo.wgs_per_cu = (e.force_cfg / 100) % 10; lo.kb = e.force_cfg >= 1000 ? 2 : 1; }
+    lo.halo = L.halo_lo + L.halo_hi;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         if (h->ev_used + 2 > h->ev_pool.size()) {
@@ -466,31 +502,31 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     }
     if (cfg == 0) {
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<128, 128, 2, 2>(p, h->stream);
+        launch_cfg<128, 128, 2, 2>(p, h->stream, lo);
     } else if (cfg == 1) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<64, 128, 2, 2>(p, h->stream);
+        launch_cfg<64, 128, 2, 2>(p, h->stream, lo);
     } else if (cfg == 5) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<64, 192, 2, 2>(p, h->stream);
+        launch_cfg<64, 192, 2, 2>(p, h->stream, lo);
     } else if (cfg == 7) {   // 64 x 192 with register-prefetched X staging
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<64, 192, 2, 2, true>(p, h->stream);
+        launch_cfg<64, 192, 2, 2, true>(p, h->stream, lo);
     } else if (cfg == 8) {   // 64 x 64 with register-prefetched X staging
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<64, 64, 2, 2, true>(p, h->stream);
+        launch_cfg<64, 64, 2, 2, true>(p, h->stream, lo);
     } else if (cfg == 9) {   // 64 x 64 tiles, 16 waves, split-K inside the workgroup
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_sk(p, h->stream);
+        launch_sk(p, h->stream, lo);
     } else if (cfg == 6) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<64, 64, 2, 2>(p, h->stream);
+        launch_cfg<64, 64, 2, 2>(p, h->stream, lo);
     } else if (cfg == 4) {   // 64 x 128 tile with register-prefetched X staging (single-round launches)
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<64, 128, 2, 2, true>(p, h->stream);
+        launch_cfg<64, 128, 2, 2, true>(p, h->stream, lo);
     } else {
         p.mtiles = (L.Cout + 31) / 32; p.ntiles = (g.nrows + 255) / 256; p.taplist = L.taplist[2]; p.nact_tab = L.nact[2]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<32, 256, 1, 4>(p, h->stream);
+        launch_cfg<32, 256, 1, 4>(p, h->stream, lo);
     }
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
@@ -661,12 +697,11 @@ void plan_voc(Bump& b, int B, int T, const int* ch, VocBufs& v) {
     }
 }
 
-constexpr int MAX_STEPS_PLAN = 64;  // time-grid buffers are planned for up to this many Euler steps
 
 size_t plan_all(ev_handle* h, char* base, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
     Bump b{base, 0, 0};
     EstBufs e; VocBufs v;
-    if (Tp > 0) plan_est(b, B, Tp, h->est.loaded ? h->est.in_ch : 2 * h->dims.n_feats + h->dims.spk_emb_dim, MAX_STEPS_PLAN, e);
+    if (Tp > 0) plan_est(b, B, Tp, h->est.loaded ? h->est.in_ch : 2 * h->dims.n_feats + h->dims.spk_emb_dim, h->max_steps, e);
     if (Tv > 0) {
         int ch[5] = {512, 256, 128, 64, 32};
         plan_voc(b, B, Tv, h->voc.loaded ? h->voc.ch : ch, v);
@@ -872,15 +907,9 @@ int run_text_encoder(ev_handle* h, const int64_t* d_ids, const int32_t* d_len, c
     const int C = w.C, nc = w.nch;
     // workspace (floats): rm | E | Xm | A | H | H1 | Y | D | D2 | QKV | ATT | FF | MU | LW
     const size_t need = (n * (1 + 3 * nc + 3 * C + 2 * w.dp1.Cout + 3 * C + C + w.ffc + 80 + 4) + 1024) * sizeof(float);
-    if (need > h->enc_ws_bytes) {
-        HIPCHK(h, hipDeviceSynchronize());
-        if (h->enc_ws) HIPCHK(h, hipFree(h->enc_ws));
-        h->enc_ws = nullptr; h->enc_ws_bytes = 0;
-        HIPCHK(h, hipMalloc((void**)&h->enc_ws, need));
-        h->enc_ws_bytes = need;
-    }
-    HIPCHK(h, hipMemsetAsync(h->enc_ws, 0, need, h->stream));     // pad rows are the convolutions' zero padding
-    Bump bp; bp.base = h->enc_ws; bp.off = 0;
+    if (scratch_acquire(h, h->enc_ws, need)) return 1;
+    HIPCHK(h, hipMemsetAsync(h->enc_ws.p, 0, need, h->stream));     // pad rows are the convolutions' zero padding
+    Bump bp; bp.base = h->enc_ws.p; bp.off = 0;
     float* rm = bp.take(n); float* E = bp.take(n * nc); float* Xm = bp.take(n * nc); float* A = bp.take(n * nc);
     float* H = bp.take(n * C); float* H1 = bp.take(n * C); float* Y = bp.take(n * C);
     float* D = bp.take(n * w.dp1.Cout); float* D2 = bp.take(n * w.dp1.Cout);
@@ -891,7 +920,7 @@ int run_text_encoder(ev_handle* h, const int64_t* d_ids, const int32_t* d_len, c
     {
         const long tot = (long)B * Tx * (nc / 4);
         hipLaunchKernelGGL(enc_embed_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, d_ids, d_len, (const float*)w.emb, w.nvocab, sqrtf((float)nc),
-                           E, Xm, nc, B, Tx, S, P);
+                           E, Xm, nc, B, Tx, S, P, h->bad_ids_dev);
     }
     HIPCHK(h, hipGetLastError());
     // prenet ConvReluNorm (:36-67): 3 x [conv k5 -> LayerNorm -> ReLU], then x_org + proj(x), masked
@@ -1001,15 +1030,9 @@ int run_denoiser(ev_handle* h, const float* d_audio, int B, int L, const float* 
     const Geom g{B * S, S, P, R};
     const size_t n = (size_t)g.nrows;
     const size_t need = (n * (256 + 1032 + 256) + 1024) * sizeof(float);
-    if (need > h->dn_ws_bytes) {
-        HIPCHK(h, hipDeviceSynchronize());
-        if (h->dn_ws) HIPCHK(h, hipFree(h->dn_ws));
-        h->dn_ws = nullptr; h->dn_ws_bytes = 0;
-        HIPCHK(h, hipMalloc((void**)&h->dn_ws, need));
-        h->dn_ws_bytes = need;
-    }
-    HIPCHK(h, hipMemsetAsync(h->dn_ws, 0, need, h->stream));
-    Bump bp; bp.base = h->dn_ws; bp.off = 0;
+    if (scratch_acquire(h, h->dn_ws, need)) return 1;
+    HIPCHK(h, hipMemsetAsync(h->dn_ws.p, 0, need, h->stream));
+    Bump bp; bp.base = h->dn_ws.p; bp.off = 0;
     float* SIG = bp.take(n * 256); float* SPEC = bp.take(n * 1032); float* OUT = bp.take(n * 256);
     hipStream_t st = h->stream;
     {
@@ -1052,7 +1075,9 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     h->dims = *dims;
     { const char* fp = getenv("EV_FUSE_PAIRS"); if (fp && *fp == '0') h->fuse_pairs = false; }
     { const char* fp = getenv("EV_FUSE128"); if (fp && *fp) h->fuse128 = atoi(fp); }
-    if (dims->n_feats != 80 || dims->channels != 256 || dims->head_dim != 64 || dims->heads < 1 || dims->heads > 8) {
+    // the shipped decoder configuration (configs/model/decoder/default.yaml: 2 heads x 64) is the only one the workspace
+    // plan and the transformer launch sequence are laid out for
+    if (dims->n_feats != 80 || dims->channels != 256 || dims->head_dim != 64 || dims->heads != 2) {
         delete h;
         return 4;
     }
@@ -1067,8 +1092,9 @@ void ev_destroy(ev_handle* h) {
     for (void* p : h->owned) hipFree(p);
     if (h->ws) hipFree(h->ws);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
-    if (h->enc_ws) hipFree(h->enc_ws);
-    if (h->dn_ws) hipFree(h->dn_ws);
+    if (h->enc_ws.p) hipFree(h->enc_ws.p);
+    if (h->dn_ws.p) hipFree(h->dn_ws.p);
+    if (h->bad_ids_host) hipHostFree(h->bad_ids_host);
     for (int i = 0; i < 2; ++i) { if (h->temb_ev[i]) hipEventDestroy(h->temb_ev[i]); if (h->temb_host[i]) hipHostFree(h->temb_host[i]); }
     delete h;
 }
@@ -1327,7 +1353,23 @@ int ev_text_encoder(ev_handle* h, const int64_t* d_ids, const int32_t* d_lengths
     if (h->enc.C > h->enc.nch && !d_spk) return fail(h, "speaker embedding required by a multi-speaker text encoder");
     if ((double)B * (Tx + 4) * 3 * h->enc.C * 4.0 >= 4294967296.0) return fail(h, "text batch exceeds the 4 GiB buffer-addressing limit: split the batch");
     h->stream = (hipStream_t)stream;
+    if (!h->bad_ids_host) {
+        HIPCHK(h, hipHostMalloc((void**)&h->bad_ids_host, 64, hipHostMallocMapped));
+        *h->bad_ids_host = 0;
+        HIPCHK(h, hipHostGetDevicePointer((void**)&h->bad_ids_dev, h->bad_ids_host, 0));
+    }
     return run_text_encoder(h, d_ids, d_lengths, d_spk, B, Tx, d_mu, d_logw);
+}
+
+int ev_text_encoder_status(ev_handle* h, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    if (h->bad_ids_host && *(volatile int*)h->bad_ids_host) {
+        *(volatile int*)h->bad_ids_host = 0;
+        return fail(h, "index out of range in self: a token id passed to ev_text_encoder is outside [0, %d)", h->enc.nvocab);
+    }
+    return 0;
 }
 
 size_t ev_workspace_bytes(ev_handle* h, int B, int Tp_cfm, int T_voc) {
@@ -1346,7 +1388,9 @@ int ev_cfm_decode(ev_handle* h, const float* d_mu, const int32_t* d_lengths, con
     if (!h) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     if (check_cfm_args(h, B, Tp)) return 1;
-    if (n_steps <= 0 || n_steps > MAX_STEPS_PLAN) return fail(h, "n_steps %d out of range [1,%d]", n_steps, MAX_STEPS_PLAN);
+    if (n_steps <= 0 || n_steps > 65536) return fail(h, "n_steps %d must be positive (cli.py:143) and at most 65536", n_steps);
+    // the reference has no upper limit on n_timesteps: the per-step time-embedding buffers are re-planned when a call asks for more
+    while (n_steps > h->max_steps) { h->max_steps *= 2; h->ws_B = -1; }
     if (!d_mu || !d_z || !d_out || (h->dims.spk_emb_dim > 0 && !d_spk)) return fail(h, "null tensor argument");
     h->stream = (hipStream_t)stream;
     EstBufs b;
@@ -1409,7 +1453,7 @@ int ev_align(ev_handle* h, const float* d_wceil, const float* d_mu_x, const int3
 int ev_stft_magnitude(ev_handle* h, const float* d_audio, int B, int L, float* d_mag, void* stream) {
     if (!h) return 1;
     HIPCHK(h, hipSetDevice(h->device));
-    if (B <= 0 || L < 1024 || (L & 255) || !d_audio || !d_mag) return fail(h, "bad arguments B=%d L=%d (L must be a multiple of 256, >= 1024)", B, L);
+    if (B <= 0 || L < 768 || (L & 255) || !d_audio || !d_mag) return fail(h, "bad arguments B=%d L=%d (L must be a multiple of 256, >= 768: reflect padding of 512 needs more than 512 samples, as in torch.stft)", B, L);
     h->stream = (hipStream_t)stream;
     return run_denoiser(h, d_audio, B, L, nullptr, 0.f, nullptr, d_mag);
 }
@@ -1417,7 +1461,7 @@ int ev_stft_magnitude(ev_handle* h, const float* d_audio, int B, int L, float* d
 int ev_denoise(ev_handle* h, const float* d_audio, int B, int L, const float* d_bias_spec, float strength, float* d_out, void* stream) {
     if (!h) return 1;
     HIPCHK(h, hipSetDevice(h->device));
-    if (B <= 0 || L < 1024 || (L & 255) || !d_audio || !d_bias_spec || !d_out) return fail(h, "bad arguments B=%d L=%d (L must be a multiple of 256, >= 1024)", B, L);
+    if (B <= 0 || L < 768 || (L & 255) || !d_audio || !d_bias_spec || !d_out) return fail(h, "bad arguments B=%d L=%d (L must be a multiple of 256, >= 768: reflect padding of 512 needs more than 512 samples, as in torch.stft)", B, L);
     if ((double)B * (L / 256 + 12) * 1032 * 4.0 >= 4294967296.0) return fail(h, "audio batch exceeds the 4 GiB buffer-addressing limit: split the batch");
     h->stream = (hipStream_t)stream;
     return run_denoiser(h, d_audio, B, L, d_bias_spec, strength, d_out, nullptr);

@@ -1375,15 +1375,20 @@ __global__ void bcast_rows_kernel(const float* v, float* dst, int ld, int c0, in
 // it.  All of its convolutions run on conv_gemm_kernel; what is left is elementwise / per-frame work.
 // ---------------------------------------------------------------------------
 // token embedding * sqrt(C) (text_encoder.py:395) into frame-major rows: E = emb[id]*s (unmasked), Xm = E * mask
+// An id outside [0, nvocab) raises IndexError in the reference's nn.Embedding; here the row is computed from a clamped id (no
+// out-of-bounds read) and the event is reported through `bad` (a host-mapped word read by ev_text_encoder_status).
 __global__ void enc_embed_kernel(const int64_t* ids, const int32_t* lengths, const float* emb, int nvocab, float scale, float* E, float* Xm,
-                                 int C, int B, int Tx, int S, int P) {
+                                 int C, int B, int Tx, int S, int P, int* bad) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int c4n = C / 4;
     const int row = idx / c4n, c4 = (idx % c4n) * 4;
     if (row >= B * Tx) return;
     const int b = row / Tx, t = row % Tx;
     long id = ids[row];
-    id = id < 0 ? 0 : (id >= nvocab ? nvocab - 1 : id);
+    if (id < 0 || id >= nvocab) {
+        if (bad && c4 == 0 && t < lengths[b]) *(volatile int*)bad = 1;
+        id = id < 0 ? 0 : nvocab - 1;
+    }
     f32x4 v = *(const f32x4*)(emb + (size_t)id * C + c4);
     v *= scale;
     const size_t n = (size_t)b * S + P + t;

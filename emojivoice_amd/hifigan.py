@@ -106,12 +106,12 @@ class Generator:
             self._dirty = False
 
     @torch.inference_mode()
-    @torch.inference_mode()
     def warmup(self, frames: int = 8) -> None:
         """One tiny call: loads the code objects and allocates a first workspace (see MatchaTTS.warmup)."""
         self.forward(torch.zeros((1, 80, frames), dtype=torch.float32, device=self.device))
         torch.cuda.synchronize(self.device)
 
+    @torch.inference_mode()
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         self._sync_engine()
         return self.engine.hifigan(x.to(self.device))

@@ -120,11 +120,9 @@ class MatchaTTS:
         raise NotImplementedError("training forward (matcha_tts.py:154-246) is out of scope of the inference hot path")
 
     # ---- the hot call ------------------------------------------------------------
-    @torch.inference_mode()
-    def synthesise(self, x, x_lengths, n_timesteps, temperature=1.0, spks=None, length_scale=1.0, *, z=None):
-        """Reference matcha_tts.py:77-152.  Extension: keyword-only ``z`` (unit normal, (B, 80, Tp)) replaces the
-        internal draw for bit-reproducible parity runs."""
-        t0 = dt.datetime.now()
+    def _durations(self, x, x_lengths, spks, length_scale):
+        """matcha_tts.py:116-124: speaker embedding, text encoder, duration rounding.  Returns
+        (spk, mu_x, w_ceil, x_lengths, y_lengths) on the device; y_lengths is what fixes the padded length."""
         dev = self.device
         x, x_lengths = x.to(dev), x_lengths.to(dev)
         if self.n_spks > 1:
@@ -135,7 +133,10 @@ class MatchaTTS:
         w = torch.exp(logw) * x_mask
         w_ceil = torch.ceil(w) * length_scale
         y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
-        y_max_length = int(y_lengths.max())
+        return spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths
+
+    def _decode_aligned(self, spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths, y_max_length, n_timesteps, temperature, z=None):
+        """matcha_tts.py:125-152 for a given (possibly global, see dist.synthesise_sharded) maximum length."""
         y_max_length_ = fix_len_compatibility(y_max_length)
         y_mask = sequence_mask(y_lengths, y_max_length_).unsqueeze(1).to(x_mask.dtype)
         if self.encoder_stage == "host":
@@ -145,16 +146,26 @@ class MatchaTTS:
         else:
             mu_y, attn = self.engine.align(w_ceil, mu_x, x_lengths, y_lengths, y_max_length_)
         encoder_outputs = mu_y[:, :, :y_max_length]
-
         dec, mel = self.decode(mu_y, y_lengths, n_timesteps, temperature, spk, z=z)
-        dec = dec[:, :, :y_max_length]
-        mel = mel[:, :, :y_max_length]
+        return encoder_outputs, dec[:, :, :y_max_length], mel[:, :, :y_max_length], attn[:, :, :y_max_length]
+
+    @torch.inference_mode()
+    def synthesise(self, x, x_lengths, n_timesteps, temperature=1.0, spks=None, length_scale=1.0, *, z=None):
+        """Reference matcha_tts.py:77-152.  Extension: keyword-only ``z`` (unit normal, (B, 80, Tp)) replaces the
+        internal draw for bit-reproducible parity runs."""
+        t0 = dt.datetime.now()
+        spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths = self._durations(x, x_lengths, spks, length_scale)
+        y_max_length = int(y_lengths.max())          # the path's one host read (a device -> host sync in the reference too)
+        if self.encoder_stage != "host":
+            self.engine.text_encoder_status()        # out-of-range token id -> IndexError, as nn.Embedding raises
+        encoder_outputs, dec, mel, attn = self._decode_aligned(spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths, y_max_length,
+                                                                n_timesteps, temperature, z=z)
         t = (dt.datetime.now() - t0).total_seconds()
         rtf = t * 22050 / (dec.shape[-1] * 256)
         return {
             "encoder_outputs": encoder_outputs,
             "decoder_outputs": dec,
-            "attn": attn[:, :, :y_max_length],
+            "attn": attn,
             "mel": mel,
             "mel_lengths": y_lengths,
             "rtf": rtf,
@@ -223,12 +234,40 @@ class _Stub(dict):
         pass
 
 
-class _RestrictedUnpickler(pickle.Unpickler):
-    _ALLOWED_PREFIXES = ("torch", "collections", "numpy", "builtins", "_codecs")
+# Exact (module, name) pairs a tensor checkpoint needs.  Everything else — including the rest of ``builtins`` (eval, exec,
+# getattr, __import__ ...), ``torch`` (hub.load ...) and ``numpy`` (load ...) — resolves to the inert ``_Stub``: a pickle
+# can name any importable callable in a REDUCE, so allow-listing whole modules is arbitrary code execution.
+_ALLOWED_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "dtype"),
+    ("torch.serialization", "_get_layout"),
+    ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+    ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+    ("numpy", "dtype"), ("numpy", "ndarray"),
+    ("_codecs", "encode"),
+    ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"),
+    ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"),
+    ("builtins", "bytearray"), ("builtins", "complex"), ("builtins", "slice"),
+    ("__builtin__", "set"), ("__builtin__", "frozenset"), ("__builtin__", "dict"), ("__builtin__", "list"),
+    ("__builtin__", "tuple"), ("__builtin__", "int"), ("__builtin__", "long"), ("__builtin__", "float"),
+    ("__builtin__", "bool"), ("__builtin__", "complex"), ("__builtin__", "slice"),
+}
+_TORCH_STORAGES = {"FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage", "ShortStorage",
+                   "CharStorage", "ByteStorage", "BoolStorage", "UntypedStorage"}
+_TORCH_DTYPES = {"float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool", "float", "double",
+                 "half", "long", "int", "short"}
 
+
+class _RestrictedUnpickler(pickle.Unpickler):
     def find_class(self, module, name):
-        if module.split(".")[0] in self._ALLOWED_PREFIXES:
+        if (module, name) in _ALLOWED_GLOBALS:
+            if module == "__builtin__":
+                module, name = "builtins", ("int" if name == "long" else name)
             return super().find_class(module, name)
+        if module == "torch" and (name in _TORCH_STORAGES or name in _TORCH_DTYPES):
+            return getattr(torch, name)
         return _Stub
 
 

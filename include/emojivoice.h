@@ -29,7 +29,8 @@
  *     channel-major contiguous; waveforms are (B, 256*T) contiguous.
  *   - Every function returns 0 on success, non-zero on failure; the message is
  *     available from ev_last_error().  Nothing throws across this boundary.
- *   - One handle per (device, stream user); calls on one handle are not thread-safe.
+ *   - One handle per (device, stream user); calls on one handle are not thread-safe.  Different handles are independent:
+ *     the library keeps no mutable process-global launch state, so two host threads may drive two handles concurrently.
  */
 #ifndef EMOJIVOICE_H
 #define EMOJIVOICE_H
@@ -103,6 +104,12 @@ int ev_estimator(ev_handle *h, const float *d_x, const float *d_mu, const int32_
 int ev_text_encoder(ev_handle *h, const int64_t *d_ids, const int32_t *d_lengths, const float *d_spk, int B, int Tx,
                     float *d_mu, float *d_logw, void *stream);
 
+/* The reference's nn.Embedding raises IndexError for a token id outside [0, n_vocab) (text_encoder.py:395).  The device
+ * stage cannot raise mid-stream: it computes from a clamped id and records the event.  This call waits for `stream` and
+ * returns non-zero ("index out of range in self") if any ev_text_encoder call since the last check saw such an id among
+ * the valid tokens; the host layer calls it at its first natural synchronisation point (the read of max(y_lengths)). */
+int ev_text_encoder_status(ev_handle *h, void *stream);
+
 /* Hard monotonic alignment and expansion (utils/model.py:29-41 generate_path; matcha_tts.py:131-135):
  *   d_wceil (B, Tx) f32   ceil(exp(logw) * x_mask) * length_scale        d_mu_x (B, 80, Tx)
  *   d_xlen (B) int32, d_ylen (B) int64 (= clamp_min(sum(w_ceil), 1).long(), computed by the caller: its maximum fixes Tp)
@@ -118,7 +125,8 @@ int ev_hifigan(ev_handle *h, const float *d_mel, int B, int T, float *d_wav, voi
  * with reflect padding, evaluated as two DFT-basis convolutions on the matrix cores.
  *   ev_stft_magnitude: d_audio (B, L) -> d_mag (B, 513, L/256 + 1)     (Denoiser.__init__'s bias spectrum)
  *   ev_denoise:        d_out = ISTFT(clamp(|X| - bias*strength, 0) * exp(i*angle(X))), X = STFT(d_audio); d_bias_spec (513)
- * L must be a multiple of 256 (it is 256 * mel frames) and >= 1024. */
+ * L must be a multiple of 256 (it is 256 * mel frames) and >= 768: like torch.stft's reflect padding (512 each side), which
+ * the reference relies on, inputs of 512 samples or fewer are an error. */
 int ev_stft_magnitude(ev_handle *h, const float *d_audio, int B, int L, float *d_mag, void *stream);
 int ev_denoise(ev_handle *h, const float *d_audio, int B, int L, const float *d_bias_spec, float strength, float *d_out, void *stream);
 
@@ -127,6 +135,11 @@ int ev_denoise(ev_handle *h, const float *d_audio, int B, int L, const float *d_
  * measured on the stream the kernels run on. */
 int ev_profile_enable(ev_handle *h, int on);
 int ev_profile_read(ev_handle *h, double *conv_ms, double *conv_flops, int64_t *conv_launches, int reset);
+
+/* Kernel microbenchmark hook (tools/conv_bench.py, not part of the product path): times `iters` launches of one
+ * resblock-style conv (prologue leaky-relu, bias, residual) at a given geometry with HIP events on the default stream;
+ * dbg = ablation bits, cfg = forced tile configuration (< 0: the engine's own choice). */
+int ev_dbg_conv_bench(ev_handle *h, int Cin, int Cout, int K, int dil, int B, int T, int P, int iters, int dbg, int cfg, float *ms_out);
 
 /* ---- operator-level entry points (unit parity tests call these) ------------------
  * Activations here are frame-major (rows, C) fp32 with an explicit row stride. */
