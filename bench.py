@@ -2,11 +2,13 @@
 """EmojiVoice hot-path benchmark (BASELINE.json: audio-seconds per second per GPU and real-time
 factor, 10 Euler steps, 22.05 kHz, batch 64 synthetic 6-s utterances).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]                      config 2 (headline; N > 1 = config 3's per-GPU shape)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --config 4      ODE-step sweep {2,4,10,20,50} at batch 64: latency, mel-MSE vs n = 50 and vs the CPU oracle at the same n
+  python bench.py --config 5      streaming feel_me.py loop: 128 mixed-length utterances, all 11 emojis + default, p50 / p99 latency
 
-One "step" = CFM decode (n Euler steps of the U-Net estimator) + HiFi-GAN on one batch of B utterances per
+One "step" (config 2) = CFM decode (n Euler steps of the U-Net estimator) + HiFi-GAN on one batch of B utterances per
 GPU (inputs resident in HBM, z given, weights resident), plus — for N > 1 — the single RCCL all-gather that
 collates the waveforms.  Rank 0 prints ONE JSON line.
 """
@@ -27,6 +29,7 @@ PEAK_HBM_GBS = 8000.0
 # SURVEY.md §8(d), measured on the reference modules: FLOPs and layer-granular activation bytes per 6-s utterance
 ALG_FLOP_PER_AUDIO_S = 62.5e9
 ALG_BYTES_PER_AUDIO_S = 520e6
+TRAFFIC_JSON = ("profiles/r02_conv_hbm_traffic_pmc.json", "profiles/r01_conv_hbm_traffic_pmc.json")
 
 
 def log(*a):
@@ -56,6 +59,16 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("EV_CPU_THREADS", "32"))))
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def make_inputs(B_global, T, lo, hi, device):
     """Config 2/3 inputs: global tensors from fixed seeds; this rank keeps rows [lo, hi)."""
     from emojivoice_amd.emoji import EMOJI_MAPPING
@@ -69,72 +82,214 @@ def make_inputs(B_global, T, lo, hi, device):
     return mu.to(device), z.to(device), spk_ids.to(device), lengths.to(device)
 
 
-def cpu_baseline(sd, voc_sd, mu, z0, spk, n_ode):
-    """The CPU oracle (restatement of the reference, pinned by reference-generated goldens) timed on this
-    box's host cores on a bounded sample (the first rows) of the same workload.  ``z0`` is already scaled
-    by the temperature."""
+def oracle_rows(sd, voc_sd, mu, z0, spk, n_ode):
+    """CPU oracle on full-length rows (every length = Tp: rows do not interact): (denormalised mel, waveform).
+    ``z0`` is already scaled by the temperature."""
     from emojivoice_amd import weights as W
     from oracle import matcha_oracle as O
 
+    with torch.inference_mode():
+        mask = torch.ones(mu.shape[0], 1, mu.shape[2])
+        dec = O.solve_euler(sd, z0, mu, mask, n_ode, spk)
+        mel = O.denormalize(dec, sd["mel_mean"], sd["mel_std"])
+        return mel, O.hifigan_forward(voc_sd, mel, W.HIFIGAN_V1)
+
+
+def cpu_baseline(sd, voc_sd, mu, z0, spk, n_ode):
+    """The CPU oracle (restatement of the reference, pinned by reference-generated goldens) timed on this box's host cores
+    on a bounded sample (the first rows) of the same workload: 1 warm-up call, then the median of 3."""
     cores = host_cores()
     torch.set_num_threads(cores)
     sample_b, _, T = mu.shape
-    log(f"[bench] cpu baseline: oracle on {cores} host threads, B={sample_b} ...")
-    mask = torch.ones(sample_b, 1, T)
-
-    def run(n):
-        with torch.inference_mode():
-            dec = O.solve_euler(sd, z0[:n], mu[:n], mask[:n], n_ode, spk[:n] if spk is not None else None)
-            mel = O.denormalize(dec, sd["mel_mean"], sd["mel_std"])
-            return mel, O.hifigan_forward(voc_sd, mel, W.HIFIGAN_V1)
-
-    run(1)                                   # warm-up (thread pool, oneDNN primitives): one utterance, ~1-2 s
+    log(f"[bench] cpu baseline: oracle on {cores} host threads ({cpu_model()}), B={sample_b} ...")
+    oracle_rows(sd, voc_sd, mu[:1], z0[:1], spk[:1] if spk is not None else None, n_ode)      # warm-up: thread pool, oneDNN primitives
     times = []
-    for _ in range(2):                       # two timed calls on the full sample, the faster one is reported
+    for _ in range(3):
         t0 = time.perf_counter()
-        mel, wav = run(sample_b)
+        mel, wav = oracle_rows(sd, voc_sd, mu, z0, spk, n_ode)
         times.append(time.perf_counter() - t0)
-    dt = min(times)
+    dt = sorted(times)[1]
     audio_s = sample_b * T * HOP / SR
-    return {"value": round(audio_s / dt, 3), "unit": "audio_s/s", "cores": cores, "kind": "port",
+    return {"value": round(audio_s / dt, 3), "unit": "audio_s/s", "cores": cores, "cpu_model": cpu_model(), "kind": "port",
             "sample": f"first {sample_b} utterances of the batch (T={T} frames), {n_ode} Euler steps + HiFi-GAN; 1-utterance warm-up, "
-                      f"best of 2 calls ({times[0]:.1f} / {times[1]:.1f} s wall)"}, mel, wav
+                      f"median of 3 calls ({' / '.join(f'{t:.1f}' for t in times)} s wall)"}, mel, wav
 
 
+def build_models(device):
+    from emojivoice_amd import weights as W
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+    from emojivoice_amd.matcha_tts import MatchaTTS
+
+    sd = W.synthetic_matcha_state()
+    voc_sd = W.synthetic_hifigan_state()
+    model = MatchaTTS(sd, device=device)
+    voc = Generator(AttrDict(v1)).to(device)
+    voc.load_state_dict(voc_sd)
+    return sd, voc_sd, model, voc
+
+
+def time_text_encoder(model, B, Lx):
+    """Text encoder + duration predictor (the stage in front of the timed region; SURVEY §8d asks for it separately):
+    device stage (ev_text_encoder) and the plain-torch host-stage variant, B utterances of Lx tokens."""
+    g = torch.Generator().manual_seed(77)
+    ids = torch.randint(1, model.n_vocab, (B, Lx), generator=g).to(model.device)
+    xl = torch.full((B,), Lx, dtype=torch.long, device=model.device)
+    spk = model._sd["spk_emb.weight"][torch.randint(0, model.n_spks, (B,), generator=g).to(model.device)] if model.n_spks > 1 else None
+    out = {}
+    for stage in ("device", "host"):
+        model.encoder_stage = stage
+        for _ in range(2):
+            model.encode(ids, xl, spk)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            model.encode(ids, xl, spk)
+        torch.cuda.synchronize()
+        out[stage] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    model.encoder_stage = "device"
+    return {"batch": B, "tokens": Lx, "device_stage_ms": out["device"], "torch_stage_ms": out["host"]}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 4: ODE-step sweep at batch 64
+# ---------------------------------------------------------------------------------------------------------------------
+def run_config4(args, device):
+    sd, voc_sd, model, voc = build_models(device)
+    B, T = args.batch, args.frames
+    mu, z, spk_ids, lengths = make_inputs(B, T, 0, B, device)
+    spk = model._sd["spk_emb.weight"][spk_ids]
+    z = z * 0.667
+    s = min(args.cpu_sample, 2, B)
+    outs, rows = {}, []
+    for n in (50, 2, 4, 10, 20):
+        model.engine.cfm_decode(mu, lengths, spk, z, n)                # warm (workspace, code objects)
+        torch.cuda.synchronize()
+        t_cfm, t_voc = [], []
+        for _ in range(args.steps):
+            t0 = time.perf_counter()
+            dec = model.engine.cfm_decode(mu, lengths, spk, z, n)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            voc(dec * model.mel_std + model.mel_mean)
+            torch.cuda.synchronize()
+            t_cfm.append(t1 - t0)
+            t_voc.append(time.perf_counter() - t1)
+        outs[n] = dec
+        rows.append((n, sorted(t_cfm)[len(t_cfm) // 2], sorted(t_voc)[len(t_voc) // 2]))
+    from oracle import matcha_oracle as O
+
+    res = []
+    torch.set_num_threads(host_cores())
+    for n, t_cfm, t_voc in sorted(rows):
+        with torch.inference_mode():
+            ref = O.solve_euler(sd, z[:s].cpu(), mu[:s].cpu(), torch.ones(s, 1, T), n, spk[:s].cpu())   # CPU restatement at the same n
+        res.append({"ode_steps": n, "cfm_ms": round(t_cfm * 1e3, 2), "hifigan_ms": round(t_voc * 1e3, 2),
+                    "audio_s_per_s": round(B * T * HOP / SR / (t_cfm + t_voc), 1),
+                    "mel_mse_vs_50": float(((outs[n] - outs[50]) ** 2).mean()),
+                    "mel_mse_vs_cpu_same_n": float(((outs[n][:s].cpu() - ref) ** 2).mean()),
+                    "mel_linf_vs_cpu_same_n": float((outs[n][:s].cpu() - ref).abs().max())})
+        log(f"[bench] config4 n={n}: {res[-1]}")
+    r10 = [r for r in res if r["ode_steps"] == 10][0]
+    print(json.dumps({
+        "metric": "audio_seconds_per_second", "value": r10["audio_s_per_s"], "unit": "audio_s/s", "n_gpus": 1, "steps": args.steps, "warmup": 1,
+        "ms_per_step": round(r10["cfm_ms"] + r10["hifigan_ms"], 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"config4: ODE-step sweep {{2,4,10,20,50}} at batch {B} x {T} frames, CFM decode then HiFi-GAN back to back; "
+                               "`value` is the n = 10 point", "global_batch": B, "frames": T},
+        "sweep": res, "mse_note": f"mel-MSE on decoder outputs; vs_cpu_same_n on the first {s} rows against the CPU oracle at the same n"}), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 5: streaming loop
+# ---------------------------------------------------------------------------------------------------------------------
+_WORDS = ("the of and to in is that it was for on are as with his they at be this from have or by one had not but what all were when we "
+          "there can an your which their said if do will each about how up out them then she many some so these would other into has more "
+          "her two like him see time could no make than first been its who now people my made over did down only way find use may water "
+          "long little very after words called just where most know").split()
+
+
+def run_config5(args, device):
+    """feel_me.py main loop, TTS leg: 128 LLM-style responses of mixed length, emoji cycling through
+    the 11 mapped ones + an unmapped one; per utterance: text on the host -> ids -> text encoder -> 10-step CFM at
+    SPEAKING_RATE 0.8 -> HiFi-GAN -> clamp -> denoiser -> waveform on the host."""
+    import numpy as np
+
+    from emojivoice_amd import streaming as S
+    from emojivoice_amd.denoiser import Denoiser
+    from emojivoice_amd.emoji import EMOJI_MAPPING
+
+    sd, voc_sd, model, voc = build_models(device)
+    den = Denoiser(voc, mode="zeros")
+    tts = S.EmojiTTS(model, voc, den, text_to_ids=S.table_front_end)
+    g = torch.Generator().manual_seed(4321)
+    emojis = list(EMOJI_MAPPING.keys()) + ["\U0001F60A"]
+    n_utt = args.utterances
+    nwords = torch.randint(2, 40, (n_utt,), generator=g).tolist()
+    resp = []
+    for i, nw in enumerate(nwords):
+        ws = [_WORDS[int(k)] for k in torch.randint(0, len(_WORDS), (nw,), generator=g)]
+        resp.append(" ".join(ws) + " " + emojis[i % len(emojis)])
+    model.warmup()
+    voc.warmup()
+    tts.respond("warm up " + emojis[0])
+    torch.cuda.synchronize()
+    lat, audio, frames = [], [], []
+    for r in resp:
+        t0 = time.perf_counter()
+        out = tts.respond(r)                       # ends with the waveform on the host (.cpu())
+        lat.append(time.perf_counter() - t0)
+        n = int(out["mel_lengths"][0])
+        frames.append(n)
+        audio.append(n * HOP / SR)
+    lat, audio = np.array(lat), np.array(audio)
+    p50, p99 = float(np.percentile(lat, 50)) * 1e3, float(np.percentile(lat, 99)) * 1e3
+    print(json.dumps({
+        "metric": "streaming_tts_latency_p50_ms", "value": round(p50, 2), "unit": "ms", "n_gpus": 1, "steps": n_utt, "warmup": 1,
+        "ms_per_step": round(float(lat.mean()) * 1e3, 2), "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"config5: feel_me.py TTS loop, {n_utt} utterances B=1, {min(frames)}-{max(frames)} mel frames, 11 emoji voices + default, "
+                               "length_scale 0.8, 10 Euler steps, temperature 0.667, HiFi-GAN + clamp + denoiser, text on host -> waveform on host"},
+        "p50_ms": round(p50, 2), "p99_ms": round(p99, 2), "mean_ms": round(float(lat.mean()) * 1e3, 2), "max_ms": round(float(lat.max()) * 1e3, 2),
+        "mean_audio_s": round(float(audio.mean()), 2), "mean_rtf": round(float((lat / audio).mean()), 5),
+        "x_realtime_stream": round(float(audio.sum() / lat.sum()), 1)}), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 2 / 3 (default)
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5), help="BASELINE.json config (3 = config 2's per-GPU shape under torchrun)")
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=516, help="mel frames per utterance (516 = 5.99 s)")
     ap.add_argument("--ode-steps", type=int, default=10)
+    ap.add_argument("--utterances", type=int, default=128, help="config 5: utterances in the streaming loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run CFM and HiFi-GAN of each batch back to back on one stream")
     ap.add_argument("--cpu-sample", type=int, default=8)
     args = ap.parse_args()
 
     from emojivoice_amd import dist as D
-    from emojivoice_amd import weights as W
-    from emojivoice_amd.hifigan import AttrDict, Generator, v1
-    from emojivoice_amd.matcha_tts import MatchaTTS
     from emojivoice_amd.pipeline import BatchPipeline
 
     rank, world, local = D.init_from_env()
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+        raise SystemExit(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the hot path has no CPU fallback)")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    if args.config == 4:
+        return run_config4(args, device)
+    if args.config == 5:
+        return run_config5(args, device)
 
     B, T, n_ode = args.batch, args.frames, args.ode_steps
     assert T % 4 == 0
-    sd = W.synthetic_matcha_state()
-    voc_sd = W.synthetic_hifigan_state()
-    model = MatchaTTS(sd, device=device)
-    voc = Generator(AttrDict(v1)).to(device)
-    voc.load_state_dict(voc_sd)
+    sd, voc_sd, model, voc = build_models(device)
     lo, hi = D.shard_bounds(B * world, rank, world)
     mu, z, spk_ids, lengths = make_inputs(B * world, T, lo, hi, device)
     spk = model._sd["spk_emb.weight"][spk_ids]
@@ -142,21 +297,23 @@ def main():
 
     def step_local():
         dec = model.engine.cfm_decode(mu, lengths, spk, z, n_ode, model.mel_std, model.mel_mean)   # denormalised mel
-        return voc(dec)
+        return voc(dec), dec
 
     # consecutive batches are software-pipelined on two HIP streams (emojivoice_amd/pipeline.py): CFM decode of batch i+1
     # on a high-priority stream while HiFi-GAN of batch i runs; --no-pipeline runs the two stages back to back instead
     pipe = None if args.no_pipeline else BatchPipeline(model, voc)
 
     def step():
+        """-> (collated waveform of the global batch, this rank's waveform block, this rank's mel)"""
         if pipe is None:
-            wav = step_local()
-            return D.all_gather_waveforms(wav) if world > 1 else wav
-        wav = pipe.submit(mu, lengths, spk, z, n_ode)
+            wav, mel = step_local()
+            return (D.all_gather_waveforms(wav, B * world) if world > 1 else wav), wav, mel
+        wav, mel = pipe.submit(mu, lengths, spk, z, n_ode, return_mel=True)
+        full = wav
         if world > 1:
             with torch.cuda.stream(pipe.vocoder_stream):
-                wav = D.all_gather_waveforms(wav)
-        return wav
+                full = D.all_gather_waveforms(wav, B * world)
+        return full, wav, mel
 
     log(f"[bench] rank {rank}/{world}: weights loaded, B={B} T={T}; warmup {args.warmup} ...")
     for _ in range(args.warmup):
@@ -168,7 +325,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        wav = step()
+        full, wav, mel = step()
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
@@ -179,9 +336,26 @@ def main():
     log(f"[bench] timed {args.steps} steps in {dt:.3f} s")
     audio_s_total = args.steps * B * world * T * HOP / SR
     value = audio_s_total / dt
+    # every rank took part: the collated block must hold B rows per rank, each rank's rows at its offset
+    ranks_seen = world
+    if world > 1:
+        seen = torch.zeros(world, dtype=torch.int64, device=device)
+        seen[rank] = 1
+        torch.distributed.all_reduce(seen)
+        ranks_seen = int((seen > 0).sum())
+        assert ranks_seen == world, f"only {ranks_seen} of {world} ranks reported"
+        assert tuple(full.shape) == (B * world, 1, T * HOP), tuple(full.shape)
+        assert torch.equal(full[lo:hi], wav), "this rank's rows are not at their global offset in the gathered block"
+    gathered_shape = list(full.shape)
 
-    out = None
     if rank == 0:
+        # ---- the same workload on the serial schedule (one stream, stages back to back): what the roofline pass below runs on
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(3):
+            step_local()
+        torch.cuda.synchronize()
+        serial_ms = (time.perf_counter() - ts) / 3 * 1e3
         # ---- roofline of the dominant kernel family (fp32-MFMA implicit-GEMM conv), measured live with HIP events
         # recorded on the launch stream around every conv launch of one extra, untimed-for-`value` step
         for e in (model.engine, voc.engine):
@@ -194,20 +368,23 @@ def main():
             e.profile_enable(False)
         conv_ms, conv_fl, conv_n = ms_c + ms_v, fl_c + fl_v, n_c + n_v
         achieved = conv_fl / (conv_ms * 1e-3) / 1e12
-        # HBM bytes per conv launch from the committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE in separate runs, FETCH doubled per the gfx950 note in MI355X_MICROARCH.md); not measurable live
+        # HBM bytes per conv launch from committed PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # in separate runs, FETCH doubled per the gfx950 note in MI355X_MICROARCH.md): NOT measured in this run
         traffic = None
-        try:
-            tj = json.load(open(os.path.join(REPO, "profiles", "r01_conv_hbm_traffic_pmc.json")))
-            if B == 64 and T == 516 and n_ode == 10:
-                traffic = {"bytes_per_launch": round(tj["hbm_MB_per_launch"] * 1e6), "GB_per_step": round(tj["hbm_GB_per_step"], 1),
-                           "source": "profiles/r01_conv_hbm_traffic_pmc.json"}
-        except Exception:
-            pass
+        for tj_path in TRAFFIC_JSON:
+            try:
+                tj = json.load(open(os.path.join(REPO, tj_path)))
+                if B == 64 and T == 516 and n_ode == 10:
+                    traffic = {"bytes_per_launch": round(tj["hbm_MB_per_launch"] * 1e6), "GB_per_step": round(tj["hbm_GB_per_step"], 1),
+                               "measured_in_this_run": False, "source": tj_path + " (builder's earlier rocprofv3 --pmc passes of this command)"}
+                    break
+            except Exception:
+                pass
         per_gpu = value / world
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "kernel": "conv_gemm_kernel + resblock_pair_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                    "schedule": "serial pass (one stream, stages back to back, see serial_ms_per_step); `value` is the two-stream pipeline",
                     "launches_per_step": int(conv_n), "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
                     "alg_gflop_per_launch": round(conv_fl / max(conv_n, 1) / 1e9, 3),
                     "conv_ms_per_step": round(conv_ms, 2), "conv_ms_cfm": round(ms_c, 2), "conv_ms_hifigan": round(ms_v, 2),
@@ -215,19 +392,25 @@ def main():
         path_roof = {"fp32_frac": round(per_gpu * ALG_FLOP_PER_AUDIO_S / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
                      "hbm_frac": round(per_gpu * ALG_BYTES_PER_AUDIO_S / (PEAK_HBM_GBS * 1e9), 4),
                      "note": "whole-path fractions from SURVEY §8(d) per-audio-second work; the fp32 MFMA roof binds"}
-        # latency of ONE batch through both stages back to back (what a single request sees; `value` is throughput)
+        # stage times of one batch (serial schedule) and the latency a single request sees
         torch.cuda.synchronize()
         tl = time.perf_counter()
-        step_local()
+        dec_l = model.engine.cfm_decode(mu, lengths, spk, z, n_ode, model.mel_std, model.mel_mean)
         torch.cuda.synchronize()
-        batch_latency_ms = (time.perf_counter() - tl) * 1e3
+        tm = time.perf_counter()
+        voc(dec_l)
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        batch_latency_ms = (te - tl) * 1e3
+        stage_ms = {"cfm_decode": round((tm - tl) * 1e3, 2), "hifigan": round((te - tm) * 1e3, 2)}
+        text_enc = time_text_encoder(model, B, 151)
         # PCIe-inclusive rate (never `value`): the same step plus the D2H copy of the waveform block into pinned host memory
         pcie = None
         try:
             host_wav = torch.empty((B,) + tuple(wav.shape[1:]), dtype=torch.float32, pin_memory=True)
             torch.cuda.synchronize()
             tp = time.perf_counter()
-            host_wav.copy_(step_local(), non_blocking=True)
+            host_wav.copy_(step_local()[0], non_blocking=True)
             torch.cuda.synchronize()
             dtp = time.perf_counter() - tp
             td = time.perf_counter()
@@ -242,11 +425,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             s = min(args.cpu_sample, B)
             cpu, ref_mel, ref_wav = cpu_baseline(sd, voc_sd, mu[:s].cpu(), z[:s].cpu(), spk[:s].cpu(), n_ode)
-            # parity of the benchmarked configuration itself: the same rows decoded as their own batch on the GPU
-            dec_s = model.engine.cfm_decode(mu[:s], lengths[:s], spk[:s], z[:s], n_ode, model.mel_std, model.mel_mean)
-            wav_s = voc(dec_s)
-            cpu["parity_mel_linf"] = float((dec_s.cpu() - ref_mel).abs().max())
-            cpu["parity_wav_rms"] = float((wav_s.cpu() - ref_wav).pow(2).mean().sqrt())
+            # parity of the TIMED output itself: the first rows of the last timed step's mel / waveform (B = 64 tile
+            # configurations, two-stream schedule) against the oracle on the same rows
+            cpu["parity_mel_linf"] = float((mel[:s].cpu() - ref_mel).abs().max())
+            cpu["parity_wav_rms"] = float((wav[:s].cpu() - ref_wav).pow(2).mean().sqrt())
+            cpu["parity_wav_linf"] = float((wav[:s].cpu() - ref_wav).abs().max())
+            cpu["parity_rows"] = f"rows 0..{s - 1} of the last timed step's output (batch {B})"
         out = {
             "metric": "audio_seconds_per_second", "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -255,8 +439,10 @@ def main():
                        "global_batch": B * world, "frames": T, "ode_steps": n_ode, "parallelism": f"dp{world}",
                        "collective": "all_gather(waveforms)" if world > 1 else "none",
                        "batch_pipeline": "off" if pipe is None else "cfm(i+1) || hifigan(i) on two streams"},
+            "ranks_seen": ranks_seen, "gathered_shape": gathered_shape,
             "per_gpu_audio_s_per_s": round(per_gpu, 2), "rtf": round(1.0 / per_gpu, 6), "x_realtime_per_gpu": round(per_gpu, 1),
-            "batch_latency_ms": round(batch_latency_ms, 2),
+            "serial_ms_per_step": round(serial_ms, 2), "batch_latency_ms": round(batch_latency_ms, 2), "stage_ms": stage_ms,
+            "text_encoder": text_enc,
             "roofline": roofline, "path_roofline": path_roof, "cpu_baseline": cpu, "pcie_inclusive": pcie,
         }
         print(json.dumps(out), flush=True)

@@ -24,9 +24,10 @@ class BatchPipeline:
         self.vocoder_stream = torch.cuda.Stream(device=dev, priority=0)
         self.last_event = None
 
-    def submit(self, mu, lengths, spk, z, n_timesteps: int) -> torch.Tensor:
+    def submit(self, mu, lengths, spk, z, n_timesteps: int, return_mel: bool = False):
         """mu / z: (B, n_feats, Tp) normalised encoder output and temperature-scaled noise (flow_matching.py:32-50),
-        lengths (B,), spk (B, spk_emb_dim).  Same arithmetic as ``MatchaTTS.decode`` + ``Generator.forward``."""
+        lengths (B,), spk (B, spk_emb_dim).  Same arithmetic as ``MatchaTTS.decode`` + ``Generator.forward``.
+        ``return_mel``: also hand back the denormalised mel the vocoder consumed (valid on ``vocoder_stream`` like the waveform)."""
         cur = torch.cuda.current_stream(self.model.device)
         self.decode_stream.wait_stream(cur)               # inputs produced on the caller's stream
         with torch.cuda.stream(self.decode_stream):
@@ -39,7 +40,7 @@ class BatchPipeline:
             wav = self.vocoder(mel)
             self.last_event = torch.cuda.Event()
             self.last_event.record(self.vocoder_stream)
-        return wav
+        return (wav, mel) if return_mel else wav
 
     def synchronize(self) -> None:
         self.decode_stream.synchronize()

@@ -152,3 +152,35 @@ def test_text_encoder_tensor_export():
         d = kc // 2
         assert t["rope_theta"].shape == (d // 2,)
         assert torch.equal(t["rope_theta"], 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d)))
+
+
+def test_checkpoint_reader_does_not_execute_pickled_callables(tmp_path):
+    """a checkpoint whose pickle REDUCEs ``builtins.eval`` / ``os.system`` must load as inert stubs (or
+    fail), never run: the reader allow-lists exact (module, name) pairs, not whole modules."""
+    import builtins
+    import os as _os
+
+    from emojivoice_amd.matcha_tts import _load_ckpt
+
+    marker = tmp_path / "pwned"
+
+    class EvalPayload:
+        def __reduce__(self):
+            return (builtins.eval, (f"open({str(marker)!r}, 'w').write('x')",))
+
+    class SystemPayload:
+        def __reduce__(self):
+            return (_os.system, (f"touch {marker}",))
+
+    class GetattrPayload:
+        def __reduce__(self):
+            return (builtins.__import__, ("subprocess",))
+
+    for proto in (2, 4):
+        for i, payload in enumerate((EvalPayload(), SystemPayload(), GetattrPayload())):
+            path = tmp_path / f"evil_{proto}_{i}.ckpt"
+            torch.save({"state_dict": {"w": torch.arange(3.0)}, "hyper_parameters": payload}, path, pickle_protocol=proto)
+            ck = _load_ckpt(str(path))
+            assert torch.equal(ck["state_dict"]["w"], torch.arange(3.0))
+            assert type(ck["hyper_parameters"]).__name__ == "_Stub"
+            assert not marker.exists()

@@ -1,0 +1,285 @@
+"""BASELINE.json configs at their real sizes on a MI355X, through the C ABI, against the CPU oracle:
+
+  config 2  batch 64 x 516 frames, 10 Euler steps + HiFi-GAN — the tensors bench.py times, on the schedule it times
+            (two-stream BatchPipeline) and back to back; rows vs the oracle and vs the oracle-checked B = 8 decode
+  config 4  ODE-step sweep: n in {2, 4, 10, 20, 50} (+ 100: beyond the old 64-step plan) vs the oracle at the same n
+  config 5  the feel_me.py streaming loop: B = 1, mixed lengths, all 11 emojis + an unmapped one, SPEAKING_RATE 0.8,
+            10 steps, temperature 0.667, clamp + denoiser — each utterance vs the oracle
+plus the engine-robustness cases of this round (two handles on two host threads, token-id validation, short denoiser input).
+"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+import bench
+from emojivoice_amd import weights as W
+from oracle import matcha_oracle as O
+
+pytestmark = pytest.mark.gpu
+MEL_GATE = 1e-4
+WAV_RMS_GATE = 1e-3
+DEV = "cuda:0"
+
+
+def _linf(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+def _rms(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).double()).pow(2).mean().sqrt())
+
+
+@pytest.fixture(scope="module")
+def sds():
+    return W.synthetic_matcha_state(), W.synthetic_hifigan_state()
+
+
+@pytest.fixture(scope="module")
+def model(sds):
+    from emojivoice_amd.matcha_tts import MatchaTTS
+
+    return MatchaTTS(sds[0], device=DEV)
+
+
+@pytest.fixture(scope="module")
+def vocoder(sds):
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+
+    g = Generator(AttrDict(v1)).to(DEV)
+    g.load_state_dict(sds[1])
+    return g
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 2 at its real size
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config2_full_batch_vs_oracle(model, vocoder, sds):
+    """B = 64 x T = 516 selects tile configurations a small batch never reaches (deep-grid 128x128 / 64x192 builds, the
+    start stagger): decode + vocode exactly bench.py's tensors, both on the timed two-stream schedule and back to back, and
+    compare rows with the CPU oracle.  Every length equals Tp, so rows do not interact in the reference either
+    (GroupNorm and attention are per utterance) and the oracle can be run on a few rows."""
+    from emojivoice_amd.pipeline import BatchPipeline
+
+    sd, voc_sd = sds
+    B, T, n_ode = 64, 516, 10
+    mu, z, spk_ids, lengths = bench.make_inputs(B, T, 0, B, torch.device(DEV))
+    spk = model._sd["spk_emb.weight"][spk_ids]
+    z = z * 0.667
+    mel = model.engine.cfm_decode(mu, lengths, spk, z, n_ode, model.mel_std, model.mel_mean)
+    wav = vocoder(mel)
+    pipe = BatchPipeline(model, vocoder)
+    wav_p = [pipe.submit(mu, lengths, spk, z, n_ode) for _ in range(3)]     # three batches in flight: cfm(i+1) || hifigan(i)
+    pipe.synchronize()
+    for w in wav_p:
+        assert torch.equal(w, wav)                                          # the timed schedule gives the same bits
+    assert wav.shape == (B, 1, 256 * T) and bool(torch.isfinite(wav).all())
+    rows = [0, 1, 62, 63]
+    r = torch.tensor(rows)
+    ref_mel, ref_wav = bench.oracle_rows(sd, voc_sd, mu.cpu()[r], z.cpu()[r], spk.cpu()[r], n_ode)
+    assert _linf(mel[r.to(DEV)], ref_mel) <= MEL_GATE
+    assert _rms(wav[r.to(DEV)], ref_wav) <= WAV_RMS_GATE / 10
+    assert _linf(wav[r.to(DEV)], ref_wav) <= 1e-3
+    assert float(ref_wav.pow(2).mean().sqrt()) > 0.05                       # the gate is not vacuous
+    # rows 0..7 against the same rows decoded as their own B = 8 batch (the slice test_gpu_parity checks row-independence on)
+    mel8 = model.engine.cfm_decode(mu[:8], lengths[:8], spk[:8], z[:8], n_ode, model.mel_std, model.mel_mean)
+    wav8 = vocoder(mel8)
+    assert _linf(mel[:8], mel8.cpu()) <= 1e-5
+    assert _linf(wav[:8], wav8.cpu()) <= 5e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 4: ODE-step sweep
+# ---------------------------------------------------------------------------------------------------------------------
+def test_config4_ode_sweep_vs_oracle(model, sds):
+    sd = sds[0]
+    g = torch.Generator().manual_seed(404)
+    B, Tp = 2, 32
+    mu = torch.randn(B, 80, Tp, generator=g)
+    z = torch.randn(B, 80, Tp, generator=g)
+    lengths = torch.tensor([32, 23])
+    mask = O.sequence_mask(lengths, Tp).unsqueeze(1).float()
+    spk = sd["spk_emb.weight"][torch.tensor([15, 54])]
+    outs, refs = {}, {}
+    for n in (2, 4, 10, 20, 50, 100):
+        refs[n] = O.cfm_decode(sd, mu * mask, mask, n, 0.667, spk, z=z)
+        outs[n], _ = model.decode((mu * mask).cuda(), lengths.cuda(), n, 0.667, spk.cuda(), z=z.cuda())
+        assert _linf(outs[n], refs[n]) <= MEL_GATE / 2, n
+    # the sweep's quality axis: mel-MSE against the 50-step output, GPU vs the same quantity on the CPU restatement
+    for n in (2, 4, 10, 20):
+        mse_gpu = float(((outs[n].cpu() - outs[50].cpu()) ** 2).mean())
+        mse_cpu = float(((refs[n] - refs[50]) ** 2).mean())
+        assert abs(mse_gpu - mse_cpu) <= 1e-6 + 1e-3 * mse_cpu, (n, mse_gpu, mse_cpu)
+    assert float(((refs[2] - refs[50]) ** 2).mean()) > float(((refs[20] - refs[50]) ** 2).mean())   # more steps, closer to n = 50
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# config 5: the streaming feel_me.py loop
+# ---------------------------------------------------------------------------------------------------------------------
+RESPONSES = [
+    "I love this so much \U0001F60D",
+    "That makes me really angry \U0001F621 please stop doing it right now",
+    "\U0001F60E cool",
+    "Oh no that is so sad \U0001F62D I am sorry to hear about your day",
+    "Sure (whatever you say) \U0001F644",
+    "What a wonderful surprise \U0001F601 thank you",
+    "Hello there \U0001F642 how are you doing today? I hope everything is going well with you and your family",
+    "Ha ha ha that is hilarious \U0001F923",
+    "Wow \U0001F62E",
+    "Well that was close \U0001F605 we nearly missed the train this morning",
+    "Hmm let me think about that for a moment \U0001F914 it is a difficult question",
+    "Hello world \U0001F60A",                       # config 1's text: the emoji is not one of the 11 -> speaker 0
+    "\U0001F642",                                   # only an emoji -> says 'nice' (feel_me.py:316-317)
+    "first wins \U0001F62D then \U0001F60D",
+]
+
+
+def test_config5_streaming_loop_vs_oracle(model, vocoder, sds):
+    from emojivoice_amd import emoji as E
+    from emojivoice_amd import streaming as S
+    from emojivoice_amd.denoiser import Denoiser
+    from emojivoice_amd.emoji import EMOJI_MAPPING
+
+    sd, voc_sd = sds
+    den = Denoiser(vocoder, mode="zeros")
+    tts = S.EmojiTTS(model, vocoder, den, text_to_ids=S.table_front_end)
+    bias = O.denoiser_bias_spec(voc_sd, W.HIFIGAN_V1)
+    seen, lens = set(), []
+    for i, resp in enumerate(RESPONSES):
+        torch.manual_seed(5000 + i)
+        out = tts.respond(resp)
+        text, spk = O.parse_emoji_response(resp, E.is_emoji, E.replace_emoji)
+        assert (out["text"], out["spk"]) == (text, spk)
+        seen.add(spk)
+        ids = torch.tensor(S.T.intersperse(S.table_front_end(text.strip()), 0))[None]
+        assert torch.equal(out["x"].cpu(), ids)
+        torch.manual_seed(5000 + i)                 # seed parity: the product draws z exactly as the reference CPU run does
+        ref = O.synthesise(sd, ids, torch.tensor([ids.shape[1]]), S.STEPS, S.TTS_TEMPERATURE, torch.tensor([spk]), S.SPEAKING_RATE)
+        assert torch.equal(out["mel_lengths"].cpu(), ref["mel_lengths"]), resp     # integer output: exact
+        assert tuple(out["mel"].shape) == tuple(ref["mel"].shape)
+        assert _linf(out["mel"], ref["mel"]) <= MEL_GATE, resp
+        ref_wav = O.to_waveform(voc_sd, W.HIFIGAN_V1, ref["mel"], bias)
+        assert tuple(out["waveform"].shape) == tuple(ref_wav.shape) == (256 * ref["mel"].shape[-1],)
+        assert _rms(out["waveform"], ref_wav) <= WAV_RMS_GATE / 10, resp
+        assert _linf(out["waveform"], ref_wav) <= 1e-3, resp
+        lens.append(int(ref["mel_lengths"][0]))
+    assert seen == set(EMOJI_MAPPING.values()) | {0}            # all 11 emoji voices + the default speaker
+    assert min(lens) < 40 and max(lens) > 300                   # mixed lengths
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# durations: the device text encoder must give the host stage's integer mel lengths
+# ---------------------------------------------------------------------------------------------------------------------
+def test_device_encoder_duration_flips(model):
+    """``mel_lengths`` are integers (ceil of exp(logw)): bit-exact is the bar.  Count, over 200 random id sequences, how
+    often the device text encoder (ev_text_encoder) and the plain-torch host stage disagree on any token's ceil()."""
+    g = torch.Generator().manual_seed(2024)
+    flips = tokens = 0
+    worst = 0.0
+    for _ in range(20):
+        B, Tx = 10, 48
+        ids = torch.randint(1, 178, (B, Tx), generator=g).cuda()
+        xl = torch.randint(8, Tx + 1, (B,), generator=g).cuda()
+        sid = torch.randint(0, 109, (B,), generator=g).cuda()
+        spk = model._sd["spk_emb.weight"][sid]
+        mu_d, logw_d = model.engine.text_encoder(ids, xl, spk)
+        mu_h, logw_h, x_mask = model.encoder(ids, xl, spk)
+        wd, wh = torch.ceil(torch.exp(logw_d) * x_mask), torch.ceil(torch.exp(logw_h) * x_mask)
+        flips += int((wd != wh).sum())
+        tokens += int(x_mask.sum())
+        worst = max(worst, float(((logw_d - logw_h) * x_mask).abs().max()))
+    print(f"duration flips: {flips} of {tokens} tokens over 200 sequences; worst |dlogw| {worst:.2e}")
+    assert worst <= 1e-4
+    assert flips <= 2, (flips, tokens)      # a flip needs exp(logw) within ~1e-6 of an integer
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# robustness
+# ---------------------------------------------------------------------------------------------------------------------
+def test_two_handles_on_two_host_threads(sds):
+    """include/emojivoice.h: different handles are independent.  Two host threads drive two handles (a k = 11 / halo 50
+    vocoder and a halo-2 decoder: the launch state that used to be process-global) on two streams at the same time; the
+    results must equal the serial run."""
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+    from emojivoice_amd.matcha_tts import MatchaTTS
+
+    m = MatchaTTS(sds[0], device=DEV)
+    v = Generator(AttrDict(v1)).to(DEV)
+    v.load_state_dict(sds[1])
+    g = torch.Generator().manual_seed(8)
+    B, Tp = 2, 64
+    mu = torch.randn(B, 80, Tp, generator=g).cuda()
+    z = (torch.randn(B, 80, Tp, generator=g) * 0.667).cuda()
+    lengths = torch.tensor([64, 41], dtype=torch.int32).cuda()
+    spk = m._sd["spk_emb.weight"][torch.tensor([3, 77]).cuda()]
+    mel_in = (torch.randn(3, 80, 40, generator=g) * 2 - 5).cuda()
+    ref_dec = m.engine.cfm_decode(mu, lengths, spk, z, 3).cpu()
+    ref_wav = v(mel_in).cpu()
+    torch.cuda.synchronize()
+    res, errs = {}, []
+
+    def run_dec():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(6):
+                    res["dec"] = m.engine.cfm_decode(mu, lengths, spk, z, 3)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    def run_voc():
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(6):
+                    res["wav"] = v(mel_in)
+                torch.cuda.current_stream().synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=run_dec), threading.Thread(target=run_voc)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert torch.equal(res["dec"].cpu(), ref_dec)
+    assert torch.equal(res["wav"].cpu(), ref_wav)
+
+
+def test_token_id_out_of_range_raises(model):
+    """nn.Embedding raises IndexError for an id outside the table (text_encoder.py:395); so does the device stage, at the
+    path's first synchronisation point.  An out-of-range id in the PADDING of a shorter utterance is never looked at."""
+    ids = torch.tensor([[5, 9, 178 + 40, 3]]).cuda()
+    with pytest.raises(IndexError):
+        model.synthesise(ids, torch.tensor([4]).cuda(), 2, 0.667, torch.tensor([0]).cuda())
+    ok = torch.tensor([[5, 9, 7, 999]]).cuda()                     # bad id beyond x_lengths
+    out = model.synthesise(ok, torch.tensor([3]).cuda(), 2, 0.667, torch.tensor([0]).cuda())
+    assert bool(torch.isfinite(out["mel"]).all())
+
+
+def test_denoiser_three_frame_utterance(vocoder, sds):
+    """768 samples (3 mel frames) is the shortest input torch.stft's reflect padding accepts, hence the shortest the
+    reference's to_waveform can denoise; shorter inputs are an error there and here."""
+    from emojivoice_amd._lib import EvLibraryError
+    from emojivoice_amd.denoiser import Denoiser
+    from emojivoice_amd.hifigan import to_waveform
+
+    den = Denoiser(vocoder, mode="zeros")
+    mel = torch.randn(1, 80, 3, generator=torch.Generator().manual_seed(6)) * 2 - 5
+    got = to_waveform(mel.cuda(), vocoder, den)
+    ref = O.to_waveform(sds[1], W.HIFIGAN_V1, mel, O.denoiser_bias_spec(sds[1], W.HIFIGAN_V1))
+    assert tuple(got.shape) == tuple(ref.shape) == (768,)
+    assert _linf(got, ref) <= 1e-4
+    with pytest.raises(EvLibraryError):
+        to_waveform(mel[:, :, :2].cuda(), vocoder, den)           # 512 samples: torch.stft raises in the reference too
+    with pytest.raises(RuntimeError):
+        O.to_waveform(sds[1], W.HIFIGAN_V1, mel[:, :, :2], O.denoiser_bias_spec(sds[1], W.HIFIGAN_V1))
+
+
+def test_unsupported_head_count_is_refused():
+    from emojivoice_amd._lib import Engine, EvLibraryError
+
+    with pytest.raises(EvLibraryError):
+        Engine(0, spk_emb_dim=64, heads=4)
