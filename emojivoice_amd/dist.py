@@ -115,8 +115,7 @@ def synthesise_sharded(model, vocoder, x, x_lengths, n_timesteps, temperature=1.
     dev = model.device
     xs, xls = x[lo:hi], x_lengths[lo:hi]
     sp = spks[lo:hi] if spks is not None else None
-    spk, mu_x, w_ceil, x_mask, xls_d, y_lengths = model._durations(xs, xls, sp, length_scale)
-    y_max_local = int(y_lengths.max())
+    spk, mu_x, w_ceil, x_mask, xls_d, y_lengths, y_max_local = model._durations(xs, xls, sp, length_scale)
     if model.encoder_stage != "host":
         model.engine.text_encoder_status()
     Tp = global_padded_length(y_max_local, device=dev if (world > 1 and dist.get_backend() == "nccl") else None)

@@ -121,8 +121,8 @@ class MatchaTTS:
 
     # ---- the hot call ------------------------------------------------------------
     def _durations(self, x, x_lengths, spks, length_scale):
-        """matcha_tts.py:116-124: speaker embedding, text encoder, duration rounding.  Returns
-        (spk, mu_x, w_ceil, x_lengths, y_lengths) on the device; y_lengths is what fixes the padded length."""
+        """matcha_tts.py:116-125: speaker embedding, text encoder, duration rounding.  Returns
+        (spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths) on the device and max(y_lengths) as a host int."""
         dev = self.device
         x, x_lengths = x.to(dev), x_lengths.to(dev)
         if self.n_spks > 1:
@@ -132,8 +132,12 @@ class MatchaTTS:
         mu_x, logw, x_mask = self.encode(x, x_lengths, spk)
         w = torch.exp(logw) * x_mask
         w_ceil = torch.ceil(w) * length_scale
-        y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
-        return spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths
+        # y_lengths is an INTEGER output (truncation of a float sum): with a fractional length_scale the sum sits on or next to
+        # an integer (55 x 0.8 = 44) and the summation order decides the truncation.  The reduction is therefore done by the same
+        # torch CPU op the reference CPU run uses, on the (B, Tx) durations copied to the host — the copy replaces the
+        # device -> host read of max(y_lengths) that the path needs anyway (matcha_tts.py:125), so it adds no synchronisation.
+        y_lengths_host = torch.clamp_min(torch.sum(w_ceil.cpu(), [1, 2]), 1).long()
+        return spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths_host.to(dev), int(y_lengths_host.max())
 
     def _decode_aligned(self, spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths, y_max_length, n_timesteps, temperature, z=None):
         """matcha_tts.py:125-152 for a given (possibly global, see dist.synthesise_sharded) maximum length."""
@@ -154,8 +158,7 @@ class MatchaTTS:
         """Reference matcha_tts.py:77-152.  Extension: keyword-only ``z`` (unit normal, (B, 80, Tp)) replaces the
         internal draw for bit-reproducible parity runs."""
         t0 = dt.datetime.now()
-        spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths = self._durations(x, x_lengths, spks, length_scale)
-        y_max_length = int(y_lengths.max())          # the path's one host read (a device -> host sync in the reference too)
+        spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths, y_max_length = self._durations(x, x_lengths, spks, length_scale)
         if self.encoder_stage != "host":
             self.engine.text_encoder_status()        # out-of-range token id -> IndexError, as nn.Embedding raises
         encoder_outputs, dec, mel, attn = self._decode_aligned(spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths, y_max_length,

@@ -125,7 +125,8 @@ class _OracleModel:
         spk = torch.nn.functional.embedding(spks.long(), self.sd["spk_emb.weight"])
         mu_x, logw, x_mask = O.text_encoder(self.sd, x, x_lengths, spk)
         w_ceil = torch.ceil(torch.exp(logw) * x_mask) * length_scale
-        return spk, mu_x, w_ceil, x_mask, x_lengths, torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+        y_lengths = torch.clamp_min(torch.sum(w_ceil, [1, 2]), 1).long()
+        return spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths, int(y_lengths.max())
 
     def _decode_aligned(self, spk, mu_x, w_ceil, x_mask, x_lengths, y_lengths, y_max_length, n_timesteps, temperature, z=None):
         O = self.O
@@ -163,7 +164,7 @@ def _synth_body(rank, world, port, q):
     e_mel = float((out["mel"][:, :, :n] - ref["mel"][lo:hi]).abs().max())
     # the sharded run vocodes the untrimmed Tp-frame mel: build the same thing for the whole batch in one process
     torch.manual_seed(4242)
-    _, _, mel_tp, _ = model._decode_aligned(*model._durations(ids, xl, spks, 1.0), Tp, 2, 0.667, z=model.draw_noise(B, Tp))
+    _, _, mel_tp, _ = model._decode_aligned(*model._durations(ids, xl, spks, 1.0)[:6], Tp, 2, 0.667, z=model.draw_noise(B, Tp))
     ref_wav = O.hifigan_forward(voc_sd, mel_tp, W.HIFIGAN_V1).clamp(-1, 1)
     e_wav = float((out["wav"] - ref_wav).abs().max())
     same_len = bool(torch.equal(out["mel_lengths"], ref["mel_lengths"]))

@@ -156,7 +156,13 @@ def test_config5_streaming_loop_vs_oracle(model, vocoder, sds):
         assert torch.equal(out["x"].cpu(), ids)
         torch.manual_seed(5000 + i)                 # seed parity: the product draws z exactly as the reference CPU run does
         ref = O.synthesise(sd, ids, torch.tensor([ids.shape[1]]), S.STEPS, S.TTS_TEMPERATURE, torch.tensor([spk]), S.SPEAKING_RATE)
-        assert torch.equal(out["mel_lengths"].cpu(), ref["mel_lengths"]), resp     # integer output: exact
+        if not torch.equal(out["mel_lengths"].cpu(), ref["mel_lengths"]):          # integer output: exact; say which stage disagreed
+            spk_e = torch.nn.functional.embedding(torch.tensor([spk]), sd["spk_emb.weight"])
+            _, rlogw, rmask = O.text_encoder(sd, ids, torch.tensor([ids.shape[1]]), spk_e)
+            _, dlogw = model.engine.text_encoder(ids.cuda(), torch.tensor([ids.shape[1]]).cuda(), spk_e.cuda())
+            nflip = int((torch.ceil(torch.exp(rlogw)) != torch.ceil(torch.exp(dlogw.cpu()))).sum())
+            raise AssertionError(f"mel_lengths {out['mel_lengths'].tolist()} vs {ref['mel_lengths'].tolist()} for {resp!r}: {nflip} ceil() flips, "
+                                 f"max |dlogw| {float((rlogw - dlogw.cpu()).abs().max()):.2e}")
         assert tuple(out["mel"].shape) == tuple(ref["mel"].shape)
         assert _linf(out["mel"], ref["mel"]) <= MEL_GATE, resp
         ref_wav = O.to_waveform(voc_sd, W.HIFIGAN_V1, ref["mel"], bias)
