@@ -116,6 +116,8 @@ struct ev_handle {
     bool prof = false;
     bool fuse_pairs = true;     // EV_FUSE_PAIRS=0 disables resblock_pair_kernel (A/B runs)
     int fuse128 = 3;            // fuse C=128 pairs up to this kernel size (EV_FUSE128=0/3/7/11)
+    bool fuse_mlp = true;       // EV_FUSE_MLP=0: LayerNorm / QKV / feed-forward of the transformer blocks as separate launches
+    int fuse_mlp_min_tiles = 192;   // EV_FUSE_MLP_MIN=<32-row tiles>: below this the separate (split-K) launches are used
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     hipStream_t ws_stream = nullptr; bool ws_stream_valid = false;   // stream of the last call that used the workspace
     float* temb_host[2] = {nullptr, nullptr}; size_t temb_cap[2] = {0, 0}; hipEvent_t temb_ev[2] = {nullptr, nullptr}; int temb_slot = 0;
@@ -495,7 +497,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     {   // start stagger (see conv_gemm_kernel): only worth it when the grid is several rounds deep
         const int slots = cfg == 0 ? 3 : ((cfg == 1 || cfg == 5 || cfg == 7) ? 4 : ((cfg == 6 || cfg == 8) ? 5 : 3));
         const long wgs = (cfg == 5 || cfg == 7) ? (long)((L.Cout + 63) / 64) * ((g.nrows + 191) / 192) : (cfg == 6 || cfg == 8) ? (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64) : cfg == 0 ? (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) : (cfg == 1 ? (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) : (long)((L.Cout + 31) / 32) * ((g.nrows + 255) / 256));
-        p.stagger_slots = (wgs >= 256L * slots * 3) ? slots : 0;
+        p.stagger_slots = (wgs >= 256L * slots * 3 && cfg < 10) ? slots : 0;
         if (e.stagger >= 0) p.stagger_slots = e.stagger;
         static const char* senv = getenv("EV_STAGGER");
         if (senv && *senv) p.stagger_slots = atoi(senv) ? p.stagger_slots : 0;
@@ -521,6 +523,12 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     } else if (cfg == 6) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 64, 2, 2>(p, h->stream, lo);
+    } else if (cfg == 10 && !L.sparse_taps && L.Mpad % 128 == 0) {   // 128 x 192: less halo per MFMA for the wide-halo layers at Cout = 128
+        p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = 0;
+        launch_cfg<128, 192, 2, 2>(p, h->stream, lo);
+    } else if (cfg == 12 && !L.sparse_taps && L.Mpad % 256 == 0) {   // 256 x 64: every output channel of a 256-wide layer from one X tile
+        p.mtiles = L.Mpad / 256; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[0]; p.nact_tab = nullptr; p.tl_stride = 0;
+        launch_cfg<256, 64, 4, 1>(p, h->stream, lo);
     } else if (cfg == 4) {   // 64 x 128 tile with register-prefetched X staging (single-round launches)
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 128, 2, 2, true>(p, h->stream, lo);
@@ -624,6 +632,49 @@ int launch_ln(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const fl
     p.X = X; p.ldx = ldx; p.Y = Y; p.ldy = ldy; p.gamma = gamma; p.beta = beta; p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T; p.eps = 1e-5f;
     hipLaunchKernelGGL(layernorm256_kernel, dim3((g.nrows + 3) / 4), dim3(256), 0, h->stream, p);
     HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// LayerNorm + feed-forward (mode 0) or LayerNorm + QKV projection (mode 1) of one transformer block in one launch
+// (ln_mlp_kernel).  Counted as ONE conv launch of the dominant-kernel family by the profiling hooks (its FLOPs are those of
+// the linears it contains).
+int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const float* ln_b, const ConvLayer& L1, const ConvLayer* L2,
+               const float* alpha, const float* binv, const float* R, const float* rowmask, float* Y, int ldy, const Geom& g) {
+    MlpParams mp;
+    memset(&mp, 0, sizeof mp);
+    ConvParams& p = mp.ep;
+    const ConvLayer& Lout = mode == 0 ? *L2 : L1;
+    p.Y = Y; p.ldy = ldy; p.Cout = Lout.Cout; p.bias = mode == 0 ? Lout.bias : nullptr; p.osplit_log2 = 31; p.isplit_log2 = 31; p.mmul = 1;
+    p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T; p.scale = 1.f;
+    p.R = R; p.ldr = 256; p.rowmask = rowmask; p.mask2 = (mode == 0 && rowmask) ? 1 : 0;
+    mp.X = X; mp.ldx = 256; mp.ln_g = ln_g; mp.ln_b = ln_b; mp.ln_eps = 1e-5f;
+    mp.W1 = L1.W; mp.b1 = L1.bias; mp.M1 = L1.Mpad; mp.alpha = alpha; mp.binv = binv; mp.W2 = L2 ? L2->W : nullptr;
+    if (L1.Cin != 256 || L1.Kpad != 256 || L1.ntaps != 1 || (L1.Mpad % 128) || L1.Cout != L1.Mpad || (ldy & 3))
+        return fail(h, "launch_mlp: first linear must be 256 -> multiple of 128 (got %d -> %d)", L1.Cin, L1.Cout);
+    if (mode == 0 && (!L2 || L2->Cout != 256 || L2->Mpad != 256 || L2->Cin != L1.Cout || L2->Kpad != L1.Mpad || L2->ntaps != 1 || !L2->bias || !alpha || !binv))
+        return fail(h, "launch_mlp: second linear must be %d -> 256 with bias", L1.Cout);
+    if ((double)g.nrows * std::max(ldy, 256) * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
+    const int ntiles = (g.nrows + 31) / 32;
+    const size_t smem = (size_t)(32 * 260 + 4 * 32 * 36) * sizeof(float);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t ev; HIPCHK(h, hipEventCreate(&ev)); h->ev_pool.push_back(ev); }
+        }
+        e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+    }
+    if (mode == 0) hipLaunchKernelGGL(ln_mlp_kernel<0>, dim3(ntiles), dim3(256), smem, h->stream, mp);
+    else hipLaunchKernelGGL(ln_mlp_kernel<1>, dim3(ntiles), dim3(256), smem, h->stream, mp);
+    HIPCHK(h, hipGetLastError());
+    if (h->prof) {
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        const double valid_rows = (double)(g.nrows / g.S) * g.T;
+        const double fl = 2.0 * (L1.macs_per_row + (L2 ? L2->macs_per_row : 0.0)) * valid_rows;
+        h->prof_flops += fl;
+        h->prof_launches += 1;
+        h->prof_recs.push_back({2 + mode, 256, Lout.Cout, 1, g.nrows, 20 + mode, 1, fl});
+    }
     return 0;
 }
 
@@ -742,6 +793,7 @@ int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
 // estimator forward (decoder.py:363-443).  On entry X0 holds [x*m | mu*m | spk*m].
 // ---------------------------------------------------------------------------
 struct LevelBufs { float *A, *Bf, *R, *H, *LN, *QKV, *ATT, *FF; const float* rm; Geom g; float* AR; };
+inline int g_rows32(const Geom& g) { return (g.nrows + 31) / 32; }
 
 int run_resnet(ev_handle* h, const ResnetW& w, const float* X, int ldx, const LevelBufs& L, const float* temb) {
     Epi e;
@@ -764,11 +816,19 @@ int run_resnet0(ev_handle* h, const EstimatorW& W, const float* X, int ldx, cons
 // BasicTransformerBlock (transformer.py:243-316) on L.H; result (masked) -> Z with row stride ldz
 int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z, int ldz, int heads) {
     Epi e;
-    if (launch_ln(h, L.H, 256, L.LN, 256, w.ln1g, w.ln1b, L.g)) return 1;
-    if (launch_conv(h, w.qkv, L.LN, 256, L.QKV, 384, L.g, e)) return 1;
+    // row tiles of 32 frames: the fused LayerNorm + linear kernels need about a round of workgroups to pay off (a batch-1
+    // decode has 9-27 such tiles: it keeps the split-K small-launch build of the separate linears)
+    const bool fuse = h->fuse_mlp && (g_rows32(L.g) >= h->fuse_mlp_min_tiles);
+    if (fuse) {
+        if (launch_mlp(h, 1, L.H, w.ln1g, w.ln1b, w.qkv, nullptr, nullptr, nullptr, nullptr, nullptr, L.QKV, 384, L.g)) return 1;
+    } else {
+        if (launch_ln(h, L.H, 256, L.LN, 256, w.ln1g, w.ln1b, L.g)) return 1;
+        if (launch_conv(h, w.qkv, L.LN, 256, L.QKV, 384, L.g, e)) return 1;
+    }
     if (launch_attn(h, L.QKV, 384, L.ATT, 128, L.rm, L.g, heads)) return 1;
     Epi eo; eo.R = L.H; eo.ldr = 256;
     if (launch_conv(h, w.out, L.ATT, 128, L.H, 256, L.g, eo)) return 1;  // H <- attn + H (in place, element-wise aliasing only)
+    if (fuse) return launch_mlp(h, 0, L.H, w.ln3g, w.ln3b, w.ff1, &w.ff2, w.alpha, w.binv, L.H, L.rm, Z, ldz, L.g);
     if (launch_ln(h, L.H, 256, L.LN, 256, w.ln3g, w.ln3b, L.g)) return 1;
     Epi e1; e1.act = ACT_SNAKE; e1.act_a = w.alpha; e1.act_b = w.binv;
     if (launch_conv(h, w.ff1, L.LN, 256, L.FF, 1024, L.g, e1)) return 1;
@@ -1075,6 +1135,8 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     h->dims = *dims;
     { const char* fp = getenv("EV_FUSE_PAIRS"); if (fp && *fp == '0') h->fuse_pairs = false; }
     { const char* fp = getenv("EV_FUSE128"); if (fp && *fp) h->fuse128 = atoi(fp); }
+    { const char* fp = getenv("EV_FUSE_MLP"); if (fp && *fp == '0') h->fuse_mlp = false; }
+    { const char* fp = getenv("EV_FUSE_MLP_MIN"); if (fp && *fp) h->fuse_mlp_min_tiles = atoi(fp); }
     // the shipped decoder configuration (configs/model/decoder/default.yaml: 2 heads x 64) is the only one the workspace
     // plan and the transformer launch sequence are laid out for
     if (dims->n_feats != 80 || dims->channels != 256 || dims->head_dim != 64 || dims->heads != 2) {
@@ -1567,7 +1629,7 @@ int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* 
             if (FILE* f = fopen(dump, "a")) {
                 fprintf(f, "# kind Cin Cout ntaps nrows cfg lean launches total_ms TFLOP/s\n");
                 for (auto& a : aggs)
-                    fprintf(f, "%s %4d %4d %3d %9d %3d %d %5d %9.3f %7.1f\n", a.r.kind ? "pair" : "conv", a.r.Cin, a.r.Cout, a.r.ntaps, a.r.nrows, a.r.cfg, a.r.lean,
+                    fprintf(f, "%s %4d %4d %3d %9d %3d %d %5d %9.3f %7.1f\n", a.r.kind == 0 ? "conv" : (a.r.kind == 1 ? "pair" : (a.r.kind == 2 ? "lnff" : "lnqkv")), a.r.Cin, a.r.Cout, a.r.ntaps, a.r.nrows, a.r.cfg, a.r.lean,
                             a.n, a.ms, a.fl / (a.ms * 1e9));
                 fclose(f);
             }

@@ -299,37 +299,40 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     t -= p.P;
     unsigned yoff = ((unsigned)n0l * p.ldy + co) * 4u, roff = ((unsigned)n0l * p.ldr + co) * 4u;
     const unsigned ystep = (unsigned)(RPP * p.ldy) * 4u, rstep = (unsigned)(RPP * p.ldr) * 4u;
-    f32x4 rr[2][NP], ra[ACC ? 2 : 1][ACC ? NP : 1];
-    float rmk[2][NP];                                 // frame-mask values (mask1: before + R, mask2: after), one per row
+    // ONE register set for the residual / running-sum / mask rows of a slab: row q of slab j+1 is requested right after row q
+    // of slab j has been consumed, so a whole slab of loads is still in flight while the current slab is transposed and stored
+    // (vmcnt retires in order).  A second set (double buffering) cost 40-80 VGPRs in the 128 x 128 build and with them one
+    // workgroup per CU: 172 / 236 registers admit two waves per SIMD, <= 168 admit three.
+    f32x4 rr[NP], ra[ACC ? NP : 1];
+    float rmk[NP];                                    // frame-mask values (mask1: before + R, mask2: after), one per row
     const bool mk = p.mask1 || p.mask2;
     const __amdgpu_buffer_rsrc_t rM = ev_rsrc(p.rowmask);
-    int tt = t;
+    int tt = t, nn = n0l;
     unsigned ro = roff, ao = yoff;
-    auto issue_r = [&](int set, int jslab) {     // residual (and running-sum) rows of one slab (tt / ro / ao walk along with it)
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            const int n = n0l + (jslab * NP + q) * RPP;
-            const bool ok = co_ok && tt >= 0 && tt < p.T && n < p.nrows && n >= win_lo && n < win_hi;
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            rr[set][q] = z;
-            if (ok && has_r) rr[set][q] = ev_bload4(rR, ro, 0);
-            rmk[set][q] = 1.f;
-            if (ok && mk) rmk[set][q] = ev_bload1(rM, (unsigned)n * 4u, 0);
-            if constexpr (ACC) {
-                ra[set][q] = z;
-                if (ok && p.accum) ra[set][q] = ev_bload4(rY, ao, 0);
-                ao += ystep;
-            }
-            tt += RPP; while (tt >= p.S - p.P) tt -= p.S;   // (more than one wrap when an utterance is shorter than a pass: S < RPP)
-            ro += rstep;
+    auto issue_one = [&](int q) {                      // next row of the walk (tt / nn / ro / ao advance with it) into slot q
+        const bool ok = co_ok && tt >= 0 && tt < p.T && nn < p.nrows && nn >= win_lo && nn < win_hi;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rr[q] = z;
+        if (ok && has_r) rr[q] = ev_bload4(rR, ro, 0);
+        rmk[q] = 1.f;
+        if (ok && mk) rmk[q] = ev_bload1(rM, (unsigned)nn * 4u, 0);
+        if constexpr (ACC) {
+            ra[q] = z;
+            if (ok && p.accum) ra[q] = ev_bload4(rY, ao, 0);
+            ao += ystep;
         }
+        tt += RPP; while (tt >= p.S - p.P) tt -= p.S;   // (more than one wrap when an utterance is shorter than a pass: S < RPP)
+        nn += RPP;
+        ro += rstep;
     };
-    const bool pre = has_r || mk;
-    if (pre) issue_r(0, 0);
+    const bool pre = has_r || mk || (ACC && p.accum);
+    if (pre) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) issue_one(q);
+    }
     ev_lds_barrier();                                 // every wave is done reading the X tile: LDS can be reused
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        if (pre && j + 1 < TN) issue_r((j + 1) & 1, j + 1);
         // per-wave transposition through this wave's private LDS slab (ordered by the wave's own program order)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -352,11 +355,11 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
                 v[0] = fmaxf(v[0], v[0] * p.act_slope); v[1] = fmaxf(v[1], v[1] * p.act_slope);
                 v[2] = fmaxf(v[2], v[2] * p.act_slope); v[3] = fmaxf(v[3], v[3] * p.act_slope);
             }
-            if (p.mask1) v *= rmk[j & 1][q];
-            if (has_r) v += rr[j & 1][q];
-            if (p.mask2) v *= rmk[j & 1][q];
+            if (p.mask1) v *= rmk[q];
+            if (has_r) v += rr[q];
+            if (p.mask2) v *= rmk[q];
             if constexpr (ACC) {
-                v += ra[j & 1][q];
+                v += ra[q];
                 if (p.div3) { v[0] = ev_div3(v[0]); v[1] = ev_div3(v[1]); v[2] = ev_div3(v[2]); v[3] = ev_div3(v[3]); }
                 if (p.act2_lrelu) {
                     v[0] = fmaxf(v[0], v[0] * p.act2_slope); v[1] = fmaxf(v[1], v[1] * p.act2_slope);
@@ -364,6 +367,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
                 }
             }
             if (ok) ev_bstore4(rY, yoff, v);
+            if (pre && j + 1 < TN) issue_one(q);      // slot q is free: request the same row of the next slab
             t += RPP; while (t >= p.S - p.P) t -= p.S;
             yoff += ystep;
         }
@@ -1155,6 +1159,16 @@ struct LNParams {
     int nrows, S, P, T; float eps;
 };
 
+// one 256-channel row held as 4 channels per lane of a wavefront (two-pass mean / biased variance, like torch's LayerNorm)
+__device__ __forceinline__ f32x4 ev_ln256_row(f32x4 v, f32x4 g, f32x4 be, float eps) {
+    float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
+    float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f);
+    float rstd = 1.0f / sqrtf(var + eps);
+    f32x4 o = {d0 * rstd * g[0] + be[0], d1 * rstd * g[1] + be[1], d2 * rstd * g[2] + be[2], d3 * rstd * g[3] + be[3]};
+    return o;
+}
+
 __global__ __launch_bounds__(256) void layernorm256_kernel(const LNParams p) {
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1162,14 +1176,226 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const LNParams p) {
     const int t = (n % p.S) - p.P;
     if (t < 0 || t >= p.T) return;
     f32x4 v = *(const f32x4*)(p.X + (size_t)n * p.ldx + lane * 4);
-    float mean = wave_sum((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / 256.0f);
-    float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
-    float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / 256.0f);
-    float rstd = 1.0f / sqrtf(var + p.eps);
     f32x4 g = *(const f32x4*)(p.gamma + lane * 4);
     f32x4 be = *(const f32x4*)(p.beta + lane * 4);
-    f32x4 o = {d0 * rstd * g[0] + be[0], d1 * rstd * g[1] + be[1], d2 * rstd * g[2] + be[2], d3 * rstd * g[3] + be[3]};
-    *(f32x4*)(p.Y + (size_t)n * p.ldy + lane * 4) = o;
+    *(f32x4*)(p.Y + (size_t)n * p.ldy + lane * 4) = ev_ln256_row(v, g, be, p.eps);
+}
+
+// ---------------------------------------------------------------------------
+// ln_mlp_kernel: the feed-forward half (MODE 0) or the QKV projection (MODE 1) of a BasicTransformerBlock
+// (transformer.py:243-316) in ONE launch per 32-frame row tile:
+//   MODE 0:  y = x + W2 . SnakeBeta(W1 . LN(x) + b1) + b2,  * mask        (norm3 -> ff -> residual, transformer.py:300-316)
+//   MODE 1:  y = Wqkv . LN(x)                                             (norm1 -> to_q | to_k | to_v, :262-271)
+// The unfused path runs LayerNorm, Linear 256 -> 1024 (+SnakeBeta) and Linear 1024 -> 256 as three launches: two stage /
+// epilogue heads and tails per launch on a grid of about one round of workgroups, one HBM round trip of the normalised rows
+// and one of the 1024-wide hidden activations (2 x 136 MB per block at batch 64).  Here a workgroup stages its 32 x 256 input
+// rows ONCE (one latency episode), normalises them in LDS (the layernorm256_kernel arithmetic), and then runs over the hidden
+// width in chunks of 128: phase 1 computes the chunk h = SnakeBeta(W1_c . LN(x) + b1_c) into LDS (the [frame][channel] operand
+// layout), phase 2 accumulates y += W2[:, c] . h into registers that live across all chunks.  Neither intermediate touches
+// HBM.  Accumulation order over k is the unfused kernels' (bias first, k ascending), so results are bit-identical to them.
+// Weights stream from L2 in MFMA-fragment order as in conv_gemm_kernel, four k-groups ahead.
+// ---------------------------------------------------------------------------
+struct MlpParams {
+    ConvParams ep;                 // epilogue view of the LAST linear: Y / ldy / Cout / bias, R / ldr, rowmask / mask2, nrows / S / P / T
+    const float* X; int ldx;       // (rows, 256) input of the LayerNorm
+    const float* ln_g; const float* ln_b; float ln_eps;
+    const float* W1; const float* b1; int M1;        // fragment order [M1/32][256/8][64][4]; M1 a multiple of 128
+    const float* alpha; const float* binv;           // SnakeBeta vectors over the hidden width (MODE 0)
+    const float* W2;                                 // fragment order [256/32][M1/8][64][4] (MODE 0)
+};
+
+template <int MODE>   // (LDS admits three workgroups per CU: keep the register allocation at three waves per SIMD)
+__global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
+    constexpr int NT = 32, C = 256, XLD = C + 4, HC = 128, HLD = HC + 4;
+    const ConvParams& p = mp.ep;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                  // [NT][XLD] normalised input rows (B operand of phase 1)
+    float* Hs = smem + NT * XLD;                       // [NT][HLD] hidden chunk (B operand of phase 2); MODE 1: epilogue slabs
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * NT;
+    {   // tiles that contain no storable row (pure padding) do nothing
+        int t_first = (n0 % p.S) - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - (n0 % p.S) + p.P;
+        if (dist >= NT || n0 + dist >= p.nrows) return;
+    }
+    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(mp.X), rW1 = ev_rsrc(mp.W1), rW2 = ev_rsrc(mp.W2);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int nchunk = mp.M1 / HC;
+    // first weight fragments of the first phase: in flight while the input rows are staged and normalised
+    f32x4 P0, P1, P2, P3;                              // phase-1 A pipeline (one 32-row tile of W1: 1 KiB fragment per k-group)
+    {
+        const unsigned a = (unsigned)(wave * (C / 8)) * 1024u;
+        P0 = ev_bload4(rW1, wlane, a); P1 = ev_bload4(rW1, wlane, a + 1024u); P2 = ev_bload4(rW1, wlane, a + 2048u); P3 = ev_bload4(rW1, wlane, a + 3072u);
+    }
+    {   // ---- stage the 32 x 256 input rows: all loads first (one latency episode)
+        f32x4 xv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = q * 256 + tid, r = i >> 6, c4 = (i & 63) * 4, gr = n0 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gr < p.nrows) v = ev_bload4(rX, ((unsigned)gr * mp.ldx + c4) * 4u, 0);
+            xv[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = q * 256 + tid, r = i >> 6, c4 = (i & 63) * 4;
+            *(f32x4*)(Xs + r * XLD + c4) = xv[q];
+        }
+    }
+    ev_lds_barrier();
+    {   // ---- LayerNorm in place: wave w owns rows 8w .. 8w+7, one row = 4 channels per lane
+        const f32x4 g = *(const f32x4*)(mp.ln_g + lane * 4), be = *(const f32x4*)(mp.ln_b + lane * 4);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float* row = Xs + (wave * 8 + r) * XLD + lane * 4;
+            *(f32x4*)row = ev_ln256_row(*(const f32x4*)row, g, be, mp.ln_eps);
+        }
+    }
+    ev_lds_barrier();
+
+    f32x16 acc2[2][1];                                 // MODE 0: this wave's 64 output channels x 32 frames, alive across all chunks
+    f32x4 Q0[2], Q1[2], Q2[2], Q3[2];                  // phase-2 A pipeline (two 32-row tiles of W2)
+    if constexpr (MODE == 0) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bq = *(const f32x4*)(p.bias + wave * 64 + a * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc2[a][0][4 * g + e] = bq[e];
+            }
+        }
+    }
+    const float* xrow = Xs + li * XLD + 4 * lh;
+    const float* hrow = Hs + li * HLD + 4 * lh;
+    const int KG2 = mp.M1 / 8;                          // k-groups per row tile of W2
+
+    for (int hc = 0; hc < nchunk; ++hc) {
+        const int ht = hc * 4 + wave;                  // this wave's 32 hidden (MODE 1: output) channels of the chunk
+        // ================= phase 1: acc1 = W1[ht] . LN(x) + b1, K = 256 = 32 k-groups =================
+        f32x16 acc1;
+        {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+                if (mp.b1) bq = *(const f32x4*)(mp.b1 + ht * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc1[4 * g + e] = bq[e];
+            }
+        }
+        if constexpr (MODE == 0) {   // first W2 fragments of this chunk's phase 2: in flight during phase 1
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const unsigned b = (unsigned)((wave * 2 + a) * KG2 + hc * (HC / 8)) * 1024u;
+                Q0[a] = ev_bload4(rW2, wlane, b); Q1[a] = ev_bload4(rW2, wlane, b + 1024u);
+                Q2[a] = ev_bload4(rW2, wlane, b + 2048u); Q3[a] = ev_bload4(rW2, wlane, b + 3072u);
+            }
+        }
+        {
+            const unsigned abase = (unsigned)(ht * (C / 8)) * 1024u;
+            f32x4 B0 = *(const f32x4*)(xrow), B1;
+            auto mma1 = [&](const f32x4& a, const f32x4& b) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc1, 0, 0, 0);
+            };
+#pragma unroll 1
+            for (int kg = 0; kg < C / 8; kg += 4) {
+                const bool more = kg + 4 < C / 8;
+                B1 = *(const f32x4*)(xrow + (kg + 1) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mma1(P0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P0 = ev_bload4(rW1, wlane, abase + (unsigned)(kg + 4) * 1024u);
+                B0 = *(const f32x4*)(xrow + (kg + 2) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mma1(P1, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P1 = ev_bload4(rW1, wlane, abase + (unsigned)(kg + 5) * 1024u);
+                B1 = *(const f32x4*)(xrow + (kg + 3) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mma1(P2, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P2 = ev_bload4(rW1, wlane, abase + (unsigned)(kg + 6) * 1024u);
+                if (more) B0 = *(const f32x4*)(xrow + (kg + 4) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mma1(P3, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) P3 = ev_bload4(rW1, wlane, abase + (unsigned)(kg + 7) * 1024u);
+            }
+        }
+        if (hc + 1 < nchunk) {       // first W1 fragments of the NEXT chunk: in flight during the hand-over and phase 2
+            const unsigned a = (unsigned)((ht + 4) * (C / 8)) * 1024u;
+            P0 = ev_bload4(rW1, wlane, a); P1 = ev_bload4(rW1, wlane, a + 1024u); P2 = ev_bload4(rW1, wlane, a + 2048u); P3 = ev_bload4(rW1, wlane, a + 3072u);
+        }
+        if constexpr (MODE == 1) {
+            // ---- projection only: store this wave's 32 channels x 32 frames (per-wave slab in the Hs region)
+            f32x16 accs[1][1];
+            accs[0][0] = acc1;
+            conv_epilogue_lean<1, 1, 1>(p, accs, Hs + wave * (32 * 36), ht * 32, n0, lane);
+            continue;
+        } else {
+            // ---- h = SnakeBeta(acc1) into Hs[frame][hidden channel]; C/D register 4g+e is channel 8g + 4*half + e
+            f32x4 hv[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 sa = *(const f32x4*)(mp.alpha + ht * 32 + 8 * g + 4 * lh), sb = *(const f32x4*)(mp.binv + ht * 32 + 8 * g + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float v = acc1[4 * g + e]; hv[g][e] = fmaf(sb[e], ev_sin2(v * sa[e]), v); }
+            }
+            ev_lds_barrier();        // every wave is done reading the previous chunk's Hs (its phase 2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *(f32x4*)(Hs + li * HLD + wave * 32 + 8 * g + 4 * lh) = hv[g];
+            ev_lds_barrier();
+            // ================= phase 2: acc2 += W2[64 channels of this wave][chunk] . h, K = 128 = 16 k-groups =================
+            const unsigned b0 = (unsigned)((wave * 2) * KG2 + hc * (HC / 8)) * 1024u, b1o = (unsigned)KG2 * 1024u;
+            f32x4 B0 = *(const f32x4*)(hrow), B1;
+            auto mma2 = [&](const f32x4 (&a)[2], const f32x4& b) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) {
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s4], b[s4], acc2[0][0], 0, 0, 0);
+                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][s4], b[s4], acc2[1][0], 0, 0, 0);
+                }
+            };
+            auto ldQ = [&](f32x4 (&dst)[2], int kg) {
+                dst[0] = ev_bload4(rW2, wlane, b0 + (unsigned)kg * 1024u);
+                dst[1] = ev_bload4(rW2, wlane, b0 + b1o + (unsigned)kg * 1024u);
+            };
+#pragma unroll 1
+            for (int kg = 0; kg < HC / 8; kg += 4) {
+                const bool more = kg + 4 < HC / 8;
+                B1 = *(const f32x4*)(hrow + (kg + 1) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mma2(Q0, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) ldQ(Q0, kg + 4);
+                B0 = *(const f32x4*)(hrow + (kg + 2) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mma2(Q1, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) ldQ(Q1, kg + 5);
+                B1 = *(const f32x4*)(hrow + (kg + 3) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mma2(Q2, B0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) ldQ(Q2, kg + 6);
+                if (more) B0 = *(const f32x4*)(hrow + (kg + 4) * 8);
+                __builtin_amdgcn_sched_barrier(0);
+                mma2(Q3, B1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) ldQ(Q3, kg + 7);
+            }
+        }
+    }
+    if constexpr (MODE == 0) {
+        // ---- epilogue: + residual, * mask, store (the lean epilogue's first barrier also retires the last phase 2's LDS reads)
+        conv_epilogue_lean<2, 1, 1>(p, acc2, smem + wave * (32 * 68), wave * 64, n0, lane);
+    }
 }
 
 // ---------------------------------------------------------------------------

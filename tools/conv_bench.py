@@ -15,8 +15,8 @@ fn = eng.lib.ev_dbg_conv_bench
 fn.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_float)]
 B = int(os.environ.get("B", "16"))
 shapes = [  # name, Cin, Cout, K, dil, T, P
-    ("L1 k3", 256, 256, 3, 1, 4128, 32), ("L1 k11d5", 256, 256, 11, 5, 4128, 32),
-    ("L2 k3", 128, 128, 3, 1, 33024, 256), ("L2 k11d5", 128, 128, 11, 5, 33024, 256),
+    ("L1 k3", 256, 256, 3, 1, 4128, 32), ("L1 k7d3", 256, 256, 7, 3, 4128, 32), ("L1 k11d5", 256, 256, 11, 5, 4128, 32),
+    ("L2 k3", 128, 128, 3, 1, 33024, 256), ("L2 k7d3", 128, 128, 7, 3, 33024, 256), ("L2 k11d5", 128, 128, 11, 5, 33024, 256),
     ("L3 k3", 64, 64, 3, 1, 66048, 512), ("L3 k11d5", 64, 64, 11, 5, 66048, 512),
     ("L4 k3", 32, 32, 3, 1, 132096, 1024), ("L4 k7d3", 32, 32, 7, 3, 132096, 1024), ("L4 k11d5", 32, 32, 11, 5, 132096, 1024),
     ("est k3 T", 256, 256, 3, 1, 516, 2), ("est 1x1 T", 256, 1024, 1, 1, 516, 2), ("est ff2 T", 1024, 256, 1, 1, 516, 2),
@@ -26,7 +26,10 @@ variants = [(0, -1), (1, -1), (2, -1), (4, -1), (7, -1)]
 if len(sys.argv) > 1:
     variants = [tuple(int(x) for x in v.split(":")) for v in sys.argv[1:]]
 print(f"B={B}; columns: dbg:cfg -> ms (TFLOP/s)")
+only = os.environ.get("SHAPES")
 for name, cin, cout, k, d, T, P in shapes:
+    if only and not any(name.startswith(o) for o in only.split(",")):
+        continue
     bb = B if not name.startswith("est") else 64
     flops = 2.0 * cin * cout * k * bb * T
     row = []
