@@ -86,6 +86,14 @@ __device__ __forceinline__ void ev_bstore1(__amdgpu_buffer_rsrc_t r, unsigned vo
 __device__ __forceinline__ int2 ev_uniform(int2 v) {
     return make_int2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y));
 }
+// The whole tap list of an M tile (<= EV_MAX_TAPS entries) lives in ONE register pair, entry i on lane i, fetched once per
+// workgroup; entry ti is then a v_readlane with a scalar index.  Fetching an entry per tap from memory — even one tap ahead —
+// put an `s_waitcnt vmcnt(0)` at the top of every tap iteration (the entry's use must wait for a vector load, and the counter
+// retires in order), which drained the weight-fragment prefetches there: the fragment pipeline was never deeper than the
+// distance to the next tap boundary, whatever the code said.
+__device__ __forceinline__ int2 ev_tap_at(int2 tlv, int i) {
+    return make_int2(__builtin_amdgcn_readlane(tlv.x, i), __builtin_amdgcn_readlane(tlv.y, i));
+}
 
 // leaky-relu for slopes in [0, 1] (every use here): max(v, v*s) is two VALU instructions instead of compare / multiply / select
 __device__ __forceinline__ float ev_lrelu(float v, float s) {
@@ -477,7 +485,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     // are issued before the MFMAs of k-group g and first touched one k-group later — no register copies, so the
     // compiler's s_waitcnt lands at the first use and L2 / LDS latency hides under 16 MFMAs.
     f32x4 A0[TM], A1[TM], B0[TN], B1[TN];
+    // (no conditional loads anywhere in the K loop: a load under a branch — even a wave-uniform one — makes hipcc's waitcnt
+    // insertion give up counting and wait vmcnt(0) at the next use, which drains the whole fragment pipeline)
     auto ldAp = [&](f32x4 (&dst)[TM], unsigned aoff) {
+#ifdef EV_ABLATE_A_LOADS
+        if (p.dbg & 256) return;                         // tools/conv_bench.py ablation build: no weight-fragment loads (timing only)
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) dst[i] = ev_bload4(rW, wlane, aoff + (unsigned)(i * KG8 * 1024));
     };
@@ -495,7 +508,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s4], b[j][s4], acc[i][j], 0, 0, 0);
     };
     const float* bbase = Xs + (wn * (TN * 32) + li + p.halo_lo) * LDK + 4 * lh;
-    const int2 tv_first = (nact > 0) ? ev_uniform(tl[0]) : make_int2(0, 0);
+    const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
+    const int2 tv_first = ev_tap_at(tlv, 0);
     if constexpr (PF) {
         // ---- software-pipelined X staging.  The X tile of chunk c+1 is loaded into registers while chunk c's MFMAs
         // run and is written to LDS after them, so no wave ever waits for HBM inside the K loop — this is what a
@@ -543,11 +557,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             int tap = tv_first.x;
             const float* brow = bbase + tv_first.y * LDK;
             ldB(B0, brow, 0);
-            int2 tv_pre = tl[nact > 1 ? 1 : 0];                 // raw (vector) load; made uniform at its use one tap later
             for (int ti = 0; ti < nact; ++ti) {
                 const bool last_tap = (ti + 1 == nact);
-                const int2 ntv = last_tap ? tv_first : ev_uniform(tv_pre);
-                tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
+                const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
                 const float* nbrow = bbase + ntv.y * LDK;
                 const unsigned ap = a_off(tap, ch * 4);
                 const unsigned nap = a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4);
@@ -575,7 +587,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
             }
         }
     } else {
-    if (nact > 0) ldAp(A0, a_off(tv_first.x, 0));
+    // Weight fragments run one whole tap (four k-groups) ahead of the MFMAs in four statically named sets: measured with
+    // tools/conv_bench.py (dbg 256 = no fragment loads), a one-k-group-deep pipeline left 6-12 % on the table on every deep
+    // layer — halving the L2 stream (4 x 1 wave layout) recovered 1 % of it, so it is fragment LATENCY under load, not bandwidth.
+    f32x4 A2[TM], A3[TM];
+    if (nact > 0) {
+        const unsigned a0 = a_off(tv_first.x, 0);
+        ldAp(A0, a0); ldAp(A1, a0 + 1024u); ldAp(A2, a0 + 2048u); ldAp(A3, a0 + 3072u);
+    }
     unsigned xoff[XPASS];   // byte offset of this lane's 16 bytes in staging pass q (chunk 0); rows outside the tensor -> pad row 0 (zeros)
 #pragma unroll
     for (int q = 0; q < XPASS; ++q) {
@@ -632,36 +651,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         int tap = tv_first.x;
         const float* brow = bsub + tv_first.y * LDK;
         if (sub == 0) ldB(B0, brow, 0);                     // (later sub-chunks: prefetched by the last tap of the previous one)
-        int2 tv_pre = tl[nact > 1 ? 1 : 0];                 // raw (vector) load; made uniform at its use one tap later
         for (int ti = 0; ti < nact; ++ti) {
             const bool last_tap = (ti + 1 == nact);
-            const int2 ntv = last_tap ? tv_first : ev_uniform(tv_pre);
-            tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
+            const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
             const int ntap = ntv.x;
             const float* nbrow = bsub + ntv.y * LDK;
-            const unsigned ap = a_off(tap, ch * 4);                                // k-groups of this tap: +1 KiB each
-            const unsigned nap = a_off(ntap, last_tap ? ch * 4 + 4 : ch * 4);
             const bool have_next = !(last_tap && ch + 1 == nchunks);
-            // sched_barrier pins "loads of k-group g+1, then the 16 MFMAs of k-group g": hipcc otherwise sinks the
-            // prefetches into the MFMA block and waits for them a few MFMAs later
-            ldAp(A1, ap + 1024u); ldB(B1, brow, 1);
+            // fragments of the next tap (k-groups +1 KiB each); after the very last tap: a harmless re-read of the first fragments
+            const unsigned nap = have_next ? a_off(ntap, last_tap ? ch * 4 + 4 : ch * 4) : a_off(tv_first.x, 0);
+            // sched_barrier pins "loads, then the 16 MFMAs of a k-group": hipcc otherwise sinks the prefetches into the MFMA
+            // block and waits for them a few MFMAs later.  Set g is refilled with k-group g of the NEXT tap right after its MFMAs.
+            ldB(B1, brow, 1);
             __builtin_amdgcn_sched_barrier(0);
             mma(A0, B0);
             __builtin_amdgcn_sched_barrier(0);
-            ldAp(A0, ap + 2048u); ldB(B0, brow, 2);
+            ldAp(A0, nap);
+            ldB(B0, brow, 2);
             __builtin_amdgcn_sched_barrier(0);
             mma(A1, B1);
             __builtin_amdgcn_sched_barrier(0);
-            ldAp(A1, ap + 3072u); ldB(B1, brow, 3);
+            ldAp(A1, nap + 1024u);
+            ldB(B1, brow, 3);
             __builtin_amdgcn_sched_barrier(0);
-            mma(A0, B0);
+            mma(A2, B0);
             __builtin_amdgcn_sched_barrier(0);
-            if (have_next) ldAp(A0, nap);
-            if (!last_tap) ldB(B0, nbrow, 0);
-            else if (KB > 1 && sub + 1 < KB && ch + 1 < nchunks) ldB(B0, nbrow + 32, 0);   // next sub-chunk is already in LDS
+            ldAp(A2, nap + 2048u);
+            // first B fragments of the next tap (after the last tap of a chunk: a harmless read of the tile being retired,
+            // or — KB > 1 — the next sub-chunk, which is already in LDS)
+            ldB(B0, (KB > 1 && last_tap && sub + 1 < KB && ch + 1 < nchunks) ? nbrow + 32 : nbrow, 0);
             __builtin_amdgcn_sched_barrier(0);
-            mma(A1, B1);
+            mma(A3, B1);
             __builtin_amdgcn_sched_barrier(0);
+            ldAp(A3, nap + 3072u);
+            (void)tap;
             tap = ntap; brow = nbrow;
         }
     }
@@ -893,7 +915,7 @@ __global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kerne
     const unsigned wlane = (unsigned)lane * 16u;
     const __amdgpu_buffer_rsrc_t rX = ev_rsrc(p.X);
     f32x16 acc[TM][TN];
-    f32x4 A0[TM], A1[TM], B0[TN], B1[TN];
+    f32x4 A0[TM], A1[TM], A2[TM], A3[TM], B0[TN], B1[TN];
 
     // one conv phase: K loop over NCH chunks x taps with the A/B fragment pipeline of conv_gemm_kernel
     // (the accumulators start from the layer's bias when `binit` is given: C/D register 4g+e is channel 8g + 4*half + e)
@@ -924,39 +946,44 @@ __global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kerne
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][b][r] = bq[r >> 2][r & 3];
         }
-        const int2 tv_first = ev_uniform(tl[0]);
-        ldAp(A0, a_off(tv_first.x, 0));
+        const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
+        const int2 tv_first = ev_tap_at(tlv, 0);
+        {   // weight fragments one tap (four k-groups) ahead, as in conv_gemm_kernel
+            const unsigned a0 = a_off(tv_first.x, 0);
+            ldAp(A0, a0); ldAp(A1, a0 + 1024u); ldAp(A2, a0 + 2048u); ldAp(A3, a0 + 3072u);
+        }
         for (int ch = 0; ch < NCH; ++ch) {
             const float* bbase = chunk_base(ch);        // LDS row 0 of this chunk for this lane (stages + barriers inside)
             int tap = tv_first.x;
             const float* brow = bbase + tv_first.y * EV_LDK;
             ldB(B0, brow, 0);
-            int2 tv_pre = tl[nact > 1 ? 1 : 0];                 // raw (vector) load; made uniform at its use one tap later
             for (int ti = 0; ti < nact; ++ti) {
                 const bool last_tap = (ti + 1 == nact);
-                const int2 ntv = last_tap ? tv_first : ev_uniform(tv_pre);
-                tv_pre = tl[ti + 2 < nact ? ti + 2 : 0];
+                const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
                 const float* nbrow = bbase + ntv.y * EV_LDK;
-                const unsigned ap = a_off(tap, ch * 4);
-                const unsigned nap = a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4);
                 const bool have_next = !(last_tap && ch + 1 == NCH);
-                ldAp(A1, ap + 1024u); ldB(B1, brow, 1);
+                const unsigned nap = have_next ? a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4) : a_off(tv_first.x, 0);   // unconditional loads
+                ldB(B1, brow, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(A0, B0);
                 __builtin_amdgcn_sched_barrier(0);
-                ldAp(A0, ap + 2048u); ldB(B0, brow, 2);
+                ldAp(A0, nap);
+                ldB(B0, brow, 2);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(A1, B1);
                 __builtin_amdgcn_sched_barrier(0);
-                ldAp(A1, ap + 3072u); ldB(B1, brow, 3);
+                ldAp(A1, nap + 1024u);
+                ldB(B1, brow, 3);
                 __builtin_amdgcn_sched_barrier(0);
-                mma(A0, B0);
+                mma(A2, B0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (have_next) ldAp(A0, nap);
-                if (!last_tap) ldB(B0, nbrow, 0);
+                ldAp(A2, nap + 2048u);
+                ldB(B0, nbrow, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                mma(A1, B1);
+                mma(A3, B1);
                 __builtin_amdgcn_sched_barrier(0);
+                ldAp(A3, nap + 3072u);
+                (void)tap;
                 tap = ntv.x; brow = nbrow;
             }
         }
