@@ -20,8 +20,10 @@ class BatchPipeline:
     def __init__(self, model, vocoder):
         self.model, self.vocoder = model, vocoder
         dev = model.device
-        self.decode_stream = torch.cuda.Stream(device=dev, priority=-1)
-        self.vocoder_stream = torch.cuda.Stream(device=dev, priority=0)
+        import os
+        pd, pv = (int(v) for v in os.environ.get("EV_PIPE_PRIO", "-1,0").split(","))   # A/B: stream priorities (decode, vocoder)
+        self.decode_stream = torch.cuda.Stream(device=dev, priority=pd)
+        self.vocoder_stream = torch.cuda.Stream(device=dev, priority=pv)
         self.last_event = None
 
     def submit(self, mu, lengths, spk, z, n_timesteps: int, return_mel: bool = False):
