@@ -197,6 +197,7 @@ def run_config4(args, device):
         "config": {"workload": f"config4: ODE-step sweep {{2,4,10,20,50}} at batch {B} x {T} frames, CFM decode then HiFi-GAN back to back; "
                                "`value` is the n = 10 point", "global_batch": B, "frames": T},
         "sweep": res, "mse_note": f"mel-MSE on decoder outputs; vs_cpu_same_n on the first {s} rows against the CPU oracle at the same n"}), flush=True)
+    close_models(model, voc)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -252,11 +253,21 @@ def run_config5(args, device):
         "p50_ms": round(p50, 2), "p99_ms": round(p99, 2), "mean_ms": round(float(lat.mean()) * 1e3, 2), "max_ms": round(float(lat.max()) * 1e3, 2),
         "mean_audio_s": round(float(audio.mean()), 2), "mean_rtf": round(float((lat / audio).mean()), 5),
         "x_realtime_stream": round(float(audio.sum() / lat.sum()), 1)}), flush=True)
+    close_models(model, voc)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
 # config 2 / 3 (default)
 # ---------------------------------------------------------------------------------------------------------------------
+def close_models(*objs):
+    """Destroy the native handles explicitly, while the HIP runtime (and a profiler wrapped around it) is still alive."""
+    for o in objs:
+        eng = getattr(o, "engine", None)
+        if eng is not None:
+            eng.close()
+    torch.cuda.synchronize()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -449,6 +460,7 @@ def main():
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
+    close_models(model, voc)
 
 
 if __name__ == "__main__":

@@ -526,6 +526,9 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     } else if (cfg == 10 && !L.sparse_taps && L.Mpad % 128 == 0) {   // 128 x 192: less halo per MFMA for the wide-halo layers at Cout = 128
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = 0;
         launch_cfg<128, 192, 2, 2>(p, h->stream, lo);
+    } else if (cfg == 20 && L.Mpad % 128 == 0) {   // 128 x 128 with the next chunk's X tile prefetched through registers
+        p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_cfg<128, 128, 2, 2, true>(p, h->stream, lo);
     } else if (cfg == 13 && !L.sparse_taps && L.Mpad % 128 == 0) {   // 128 x 128 as 4 x 1 waves: a wave owns 32 channels x 128 frames, so a
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = 0;   // weight fragment feeds 16 MFMAs (half the L2 stream of 2 x 2)
         launch_cfg<128, 128, 4, 1>(p, h->stream, lo);

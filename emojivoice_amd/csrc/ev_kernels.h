@@ -510,97 +510,47 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     const float* bbase = Xs + (wn * (TN * 32) + li + p.halo_lo) * LDK + 4 * lh;
     const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
     const int2 tv_first = ev_tap_at(tlv, 0);
-    if constexpr (PF) {
-        // ---- software-pipelined X staging.  The X tile of chunk c+1 is loaded into registers while chunk c's MFMAs
-        // run and is written to LDS after them, so no wave ever waits for HBM inside the K loop — this is what a
-        // launch that fits the chip in ONE round of workgroups needs (every workgroup is in the same phase, nobody
-        // else covers a stall).  vmcnt retires in order, so a later weight-fragment wait would also wait for the X
-        // loads: the A pipeline is therefore three k-groups deep (four static register sets), which puts the first
-        // such wait ~3 k-groups of MFMAs behind the X loads.
-        f32x4 xv[XPASS];
-        auto x_load = [&](int ch) {
-            const int c = ch * EV_BK + sc4;
-            const bool cok = c < p.Cin;
-            const unsigned xcol = (unsigned)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1));
-#pragma unroll
-            for (int q = 0; q < XPASS; ++q) {
-                const int r = q * 32 + srow;
-                const int gr = n0 - p.halo_lo + r;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (cok && r < xrows && gr >= 0 && gr < p.nrows) v = ev_bload4(rX, ((unsigned)gr * p.ldx + xcol) * 4u, 0);
-                xv[q] = v;
-            }
-        };
-        auto x_store = [&]() {
-#pragma unroll
-            for (int q = 0; q < XPASS; ++q) {
-                const int r = q * 32 + srow;
-                f32x4 v = xv[q];
-                if (p.pro_lrelu) {
-                    v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
-                    v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
-                }
-                if (r < xrows) *(f32x4*)(Xs + r * LDK + sc4) = v;
-            }
-        };
-        f32x4 A2[TM], A3[TM];
-        x_load(0);
-        if (nact > 0) {
-            const unsigned a0 = a_off(tv_first.x, 0);
-            ldAp(A0, a0); ldAp(A1, a0 + 1024u); ldAp(A2, a0 + 2048u);
-        }
-        for (int ch = 0; ch < nchunks; ++ch) {
-            ev_lds_barrier();            // previous chunk's MFMAs are done with Xs
-            x_store();
-            ev_lds_barrier();
-            if (ch + 1 < nchunks) x_load(ch + 1);
-            int tap = tv_first.x;
-            const float* brow = bbase + tv_first.y * LDK;
-            ldB(B0, brow, 0);
-            for (int ti = 0; ti < nact; ++ti) {
-                const bool last_tap = (ti + 1 == nact);
-                const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
-                const float* nbrow = bbase + ntv.y * LDK;
-                const unsigned ap = a_off(tap, ch * 4);
-                const unsigned nap = a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4);
-                const bool have_next = !(last_tap && ch + 1 == nchunks);
-                ldAp(A3, ap + 3072u); ldB(B1, brow, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(A0, B0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (have_next) ldAp(A0, nap);
-                ldB(B0, brow, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(A1, B1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (have_next) ldAp(A1, nap + 1024u);
-                ldB(B1, brow, 3);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(A2, B0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (have_next) ldAp(A2, nap + 2048u);
-                if (!last_tap) ldB(B0, nbrow, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(A3, B1);
-                __builtin_amdgcn_sched_barrier(0);
-                tap = ntv.x; brow = nbrow;
-            }
-        }
-    } else {
     // Weight fragments run one whole tap (four k-groups) ahead of the MFMAs in four statically named sets: measured with
-    // tools/conv_bench.py (dbg 256 = no fragment loads), a one-k-group-deep pipeline left 6-12 % on the table on every deep
-    // layer — halving the L2 stream (4 x 1 wave layout) recovered 1 % of it, so it is fragment LATENCY under load, not bandwidth.
+    // tools/conv_bench.py, a one-k-group-deep pipeline left 6-12 % on the table on every deep layer (and halving the L2 stream
+    // with a 4 x 1 wave layout recovered 1 % of it: fragment LATENCY under load, not bandwidth).
     f32x4 A2[TM], A3[TM];
     if (nact > 0) {
         const unsigned a0 = a_off(tv_first.x, 0);
         ldAp(A0, a0); ldAp(A1, a0 + 1024u); ldAp(A2, a0 + 2048u); ldAp(A3, a0 + 3072u);
     }
-    unsigned xoff[XPASS];   // byte offset of this lane's 16 bytes in staging pass q (chunk 0); rows outside the tensor -> pad row 0 (zeros)
+    // ---- X staging.  Per-pass row offsets are fixed for the tile (xoff), the chunk's column base is a scalar (soffset), rows
+    // outside the tensor read the all-zero pad row 0 and passes beyond the tile's rows re-read that row: every load is
+    // UNCONDITIONAL (see the note at ldAp).  PF: the loads of chunk c+1 are issued right after chunk c's tile has been
+    // published, fly under chunk c's MFMAs and are written to LDS at the next stage, so the stage between the two barriers is
+    // LDS traffic only.  vmcnt retires in order, so the first fragment wait that also has to wait for these loads is the one
+    // for fragments requested after them — a whole tap (>= 64 MFMAs) later, thanks to the fragment pipeline above.
+    unsigned xoff[XPASS];
+    const int npass = (xrows + RPS - 1) / RPS;          // passes that carry rows of this tile (uniform)
 #pragma unroll
     for (int q = 0; q < XPASS; ++q) {
         const int gr = n0 - p.halo_lo + q * RPS + srow;
-        xoff[q] = ((gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
+        xoff[q] = ((q < npass && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
     }
+    auto x_soff = [&](int ch) -> unsigned {
+        const int c0 = ch * EV_BK;
+        return ((unsigned)(c0 >> p.isplit_log2) * p.isstride + (unsigned)(c0 & ((1 << p.isplit_log2) - 1))) * 4u;
+    };
+    f32x4 xv[PF ? XPASS : 1];
+    auto x_issue = [&](int ch) {                        // PF only: all passes of one chunk into registers
+        const unsigned soff = x_soff(ch);
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) xv[PF ? q : 0] = ev_bload4(rX, xoff[q], soff);
+    };
+    auto x_put = [&](int q, f32x4 v, int c0, bool ctail) {
+        const int r = q * RPS + srow;
+        if (ctail && c0 + sc4 >= p.Cin) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+        if (p.pro_lrelu) {
+            v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+            v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+        }
+        if (r < xrows) *(f32x4*)(Xs + r * LDK + sc4) = v;
+    };
+    if constexpr (PF) x_issue(0);
     unsigned long long ts0 = 0, acc_st = 0, acc_b1 = 0;   // dbg 2 (+16): accumulated stage / first-barrier time of this wave
     for (int ch = 0; ch < nchunks; ++ch) {
         // Memory phases (X staging, epilogue) issue few instructions but were measured to stretch 2-3x when the other
@@ -613,38 +563,32 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         if (!(p.dbg & 8)) ev_lds_barrier();  // previous chunk's MFMAs are done with Xs (dbg 8: timing-only ablation without barriers)
         if (p.dbg & 2) { const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(); acc_b1 += t1 - ts0; }
         {
-            // ---- stage the X tile of these KB k-chunks (with the optional prologue leaky-relu): all loads of a batch first.
-            // No per-chunk address arithmetic: the per-pass row offsets are fixed for the tile (xoff), the chunk's column
-            // base is a scalar (soffset), and rows outside the tensor read the all-zero pad row 0 instead of being masked.
             const int c0 = ch * EV_BK;
-            const unsigned soff = ((unsigned)(c0 >> p.isplit_log2) * p.isstride + (unsigned)(c0 & ((1 << p.isplit_log2) - 1))) * 4u;
             const bool ctail = (c0 + 32 * KB > p.Cin);       // uniform: only the last chunk of a Cin that is not a multiple of 32
+            if constexpr (PF) {
 #pragma unroll
-            for (int q0 = 0; q0 < XPASS; q0 += XG) {
-                if (q0 * RPS >= xrows) break;
-                f32x4 xv[XG];
+                for (int q = 0; q < XPASS; ++q) x_put(q, xv[PF ? q : 0], c0, ctail);
+            } else {
+                const unsigned soff = x_soff(ch);
 #pragma unroll
-                for (int q = 0; q < XG; ++q) {
-                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if ((q0 + q) * RPS < xrows && !(p.dbg & 1)) v = ev_bload4(rX, xoff[q0 + q], soff);
-                    xv[q] = v;
-                }
+                for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                    if (q0 * RPS >= xrows) break;
+                    f32x4 xg[XG];
 #pragma unroll
-                for (int q = 0; q < XG; ++q) {
-                    const int r = (q0 + q) * RPS + srow;
-                    f32x4 v = xv[q];
-                    if (ctail && c0 + sc4 >= p.Cin) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
-                    if (p.pro_lrelu) {
-                        v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
-                        v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                    for (int q = 0; q < XG; ++q) {
+                        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                        if ((q0 + q) * RPS < xrows && !(p.dbg & 1)) v = ev_bload4(rX, xoff[q0 + q], soff);
+                        xg[q] = v;
                     }
-                    if (r < xrows) *(f32x4*)(Xs + r * LDK + sc4) = v;
+#pragma unroll
+                    for (int q = 0; q < XG; ++q) x_put(q0 + q, xg[q], c0, ctail);
                 }
             }
         }
         if (!(p.dbg & 8)) ev_lds_barrier();
         __builtin_amdgcn_s_setprio(0);
         if (p.dbg & 2) acc_st += __builtin_amdgcn_s_memrealtime() - ts0;
+        if constexpr (PF) x_issue(ch + 1 < nchunks ? ch + 1 : ch);   // (after the last chunk: a harmless re-read)
         }
         const float* bsub = bbase + sub * 32;
         if ((p.dbg & 18) == 16 && ch == 0 && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
@@ -691,7 +635,6 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
         p.stamps[4 * blockIdx.x + 1] = p.stamps[4 * blockIdx.x] + acc_st;
         p.stamps[4 * blockIdx.x + 2] = p.stamps[4 * blockIdx.x] + acc_b1;
     }
-    }   // !PF
 
     __builtin_amdgcn_s_setprio(3);   // epilogue: see the note on memory phases above
     if ((p.dbg & 18) == 16 && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
