@@ -1193,23 +1193,25 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
         else dist = p.S - (n0 % p.S) + p.P;
         if (dist >= NT || n0 + dist >= p.nrows) return;
     }
-    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(mp.X), rW1 = ev_rsrc(mp.W1), rW2 = ev_rsrc(mp.W2);
+    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(mp.X), rW1 = ev_rsrc(mp.W1), rW2 = ev_rsrc(MODE == 0 ? mp.W2 : mp.W1);
     const unsigned wlane = (unsigned)lane * 16u;
     const int nchunk = mp.M1 / HC;
-    // first weight fragments of the first phase: in flight while the input rows are staged and normalised
-    f32x4 P0, P1, P2, P3;                              // phase-1 A pipeline (one 32-row tile of W1: 1 KiB fragment per k-group)
-    {
-        const unsigned a = (unsigned)(wave * (C / 8)) * 1024u;
-        P0 = ev_bload4(rW1, wlane, a); P1 = ev_bload4(rW1, wlane, a + 1024u); P2 = ev_bload4(rW1, wlane, a + 2048u); P3 = ev_bload4(rW1, wlane, a + 3072u);
-    }
+    const int KG2 = mp.M1 / 8;                          // k-groups per row tile of W2
+    // ONE set of eight fragment registers serves both phases: phase 1 (one 32-row tile of W1, 4 MFMAs per fragment) runs eight
+    // k-groups ahead, phase 2 (two row tiles of W2, 8 MFMAs per fragment pair) four — 32 MFMAs of cover either way.  In the last
+    // eight (four) k-groups of a phase every register, once consumed, is refilled with the first fragments of the NEXT phase, so
+    // the hand-over between the phases (SnakeBeta, LDS write, barriers) never waits for L2.  All loads are unconditional.
+    f32x4 F0, F1, F2, F3, F4, F5, F6, F7;
+    auto ldP = [&](int ht, int kg) { return ev_bload4(rW1, wlane, (unsigned)(ht * (C / 8) + kg) * 1024u); };
+    auto ldQ = [&](int hc, int kg, int a) { return ev_bload4(rW2, wlane, (unsigned)((wave * 2 + a) * KG2 + hc * (HC / 8) + kg) * 1024u); };
+    F0 = ldP(wave, 0); F1 = ldP(wave, 1); F2 = ldP(wave, 2); F3 = ldP(wave, 3);
+    F4 = ldP(wave, 4); F5 = ldP(wave, 5); F6 = ldP(wave, 6); F7 = ldP(wave, 7);
     {   // ---- stage the 32 x 256 input rows: all loads first (one latency episode)
         f32x4 xv[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int i = q * 256 + tid, r = i >> 6, c4 = (i & 63) * 4, gr = n0 + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gr < p.nrows) v = ev_bload4(rX, ((unsigned)gr * mp.ldx + c4) * 4u, 0);
-            xv[q] = v;
+            xv[q] = ev_bload4(rX, ((unsigned)(gr < p.nrows ? gr : 0) * mp.ldx + c4) * 4u, 0);   // (beyond the tensor: pad row 0)
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -1229,7 +1231,6 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
     ev_lds_barrier();
 
     f32x16 acc2[2][1];                                 // MODE 0: this wave's 64 output channels x 32 frames, alive across all chunks
-    f32x4 Q0[2], Q1[2], Q2[2], Q3[2];                  // phase-2 A pipeline (two 32-row tiles of W2)
     if constexpr (MODE == 0) {
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
@@ -1244,10 +1245,10 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
     }
     const float* xrow = Xs + li * XLD + 4 * lh;
     const float* hrow = Hs + li * HLD + 4 * lh;
-    const int KG2 = mp.M1 / 8;                          // k-groups per row tile of W2
 
     for (int hc = 0; hc < nchunk; ++hc) {
         const int ht = hc * 4 + wave;                  // this wave's 32 hidden (MODE 1: output) channels of the chunk
+        const int htn = hc + 1 < nchunk ? ht + 4 : wave;   // next chunk's tile (after the last chunk: a harmless re-read)
         // ================= phase 1: acc1 = W1[ht] . LN(x) + b1, K = 256 = 32 k-groups =================
         f32x16 acc1;
         {
@@ -1259,49 +1260,41 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
                 for (int e = 0; e < 4; ++e) acc1[4 * g + e] = bq[e];
             }
         }
-        if constexpr (MODE == 0) {   // first W2 fragments of this chunk's phase 2: in flight during phase 1
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const unsigned b = (unsigned)((wave * 2 + a) * KG2 + hc * (HC / 8)) * 1024u;
-                Q0[a] = ev_bload4(rW2, wlane, b); Q1[a] = ev_bload4(rW2, wlane, b + 1024u);
-                Q2[a] = ev_bload4(rW2, wlane, b + 2048u); Q3[a] = ev_bload4(rW2, wlane, b + 3072u);
-            }
-        }
         {
-            const unsigned abase = (unsigned)(ht * (C / 8)) * 1024u;
             f32x4 B0 = *(const f32x4*)(xrow), B1;
             auto mma1 = [&](const f32x4& a, const f32x4& b) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc1, 0, 0, 0);
             };
+            // one k-group: B fragment of the next k-group, 4 MFMAs, refill of the consumed register
+#define EV_P1_STEP(F, BC, BN_, I, REFILL)                                                        \
+            BN_ = *(const f32x4*)(xrow + ((kb + (I) + 1) & 31) * 8);                              \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            mma1(F, BC);                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            F = REFILL;
 #pragma unroll 1
-            for (int kg = 0; kg < C / 8; kg += 4) {
-                const bool more = kg + 4 < C / 8;
-                B1 = *(const f32x4*)(xrow + (kg + 1) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                mma1(P0, B0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P0 = ev_bload4(rW1, wlane, abase + (unsigned)(kg + 4) * 1024u);
-                B0 = *(const f32x4*)(xrow + (kg + 2) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                mma1(P1, B1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P1 = ev_bload4(rW1, wlane, abase + (unsigned)(kg + 5) * 1024u);
-                B1 = *(const f32x4*)(xrow + (kg + 3) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                mma1(P2, B0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P2 = ev_bload4(rW1, wlane, abase + (unsigned)(kg + 6) * 1024u);
-                if (more) B0 = *(const f32x4*)(xrow + (kg + 4) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                mma1(P3, B1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) P3 = ev_bload4(rW1, wlane, abase + (unsigned)(kg + 7) * 1024u);
+            for (int kb = 0; kb < 24; kb += 8) {
+                EV_P1_STEP(F0, B0, B1, 0, ldP(ht, kb + 8))  EV_P1_STEP(F1, B1, B0, 1, ldP(ht, kb + 9))
+                EV_P1_STEP(F2, B0, B1, 2, ldP(ht, kb + 10)) EV_P1_STEP(F3, B1, B0, 3, ldP(ht, kb + 11))
+                EV_P1_STEP(F4, B0, B1, 4, ldP(ht, kb + 12)) EV_P1_STEP(F5, B1, B0, 5, ldP(ht, kb + 13))
+                EV_P1_STEP(F6, B0, B1, 6, ldP(ht, kb + 14)) EV_P1_STEP(F7, B1, B0, 7, ldP(ht, kb + 15))
             }
-        }
-        if (hc + 1 < nchunk) {       // first W1 fragments of the NEXT chunk: in flight during the hand-over and phase 2
-            const unsigned a = (unsigned)((ht + 4) * (C / 8)) * 1024u;
-            P0 = ev_bload4(rW1, wlane, a); P1 = ev_bload4(rW1, wlane, a + 1024u); P2 = ev_bload4(rW1, wlane, a + 2048u); P3 = ev_bload4(rW1, wlane, a + 3072u);
+            {   // last eight k-groups: the registers go over to the next phase
+                constexpr int kb = 24;
+                if constexpr (MODE == 0) {
+                    EV_P1_STEP(F0, B0, B1, 0, ldQ(hc, 0, 0)) EV_P1_STEP(F1, B1, B0, 1, ldQ(hc, 0, 1))
+                    EV_P1_STEP(F2, B0, B1, 2, ldQ(hc, 1, 0)) EV_P1_STEP(F3, B1, B0, 3, ldQ(hc, 1, 1))
+                    EV_P1_STEP(F4, B0, B1, 4, ldQ(hc, 2, 0)) EV_P1_STEP(F5, B1, B0, 5, ldQ(hc, 2, 1))
+                    EV_P1_STEP(F6, B0, B1, 6, ldQ(hc, 3, 0)) EV_P1_STEP(F7, B1, B0, 7, ldQ(hc, 3, 1))
+                } else {
+                    EV_P1_STEP(F0, B0, B1, 0, ldP(htn, 0)) EV_P1_STEP(F1, B1, B0, 1, ldP(htn, 1))
+                    EV_P1_STEP(F2, B0, B1, 2, ldP(htn, 2)) EV_P1_STEP(F3, B1, B0, 3, ldP(htn, 3))
+                    EV_P1_STEP(F4, B0, B1, 4, ldP(htn, 4)) EV_P1_STEP(F5, B1, B0, 5, ldP(htn, 5))
+                    EV_P1_STEP(F6, B0, B1, 6, ldP(htn, 6)) EV_P1_STEP(F7, B1, B0, 7, ldP(htn, 7))
+                }
+            }
+#undef EV_P1_STEP
         }
         if constexpr (MODE == 1) {
             // ---- projection only: store this wave's 32 channels x 32 frames (per-wave slab in the Hs region)
@@ -1323,43 +1316,31 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
             for (int g = 0; g < 4; ++g) *(f32x4*)(Hs + li * HLD + wave * 32 + 8 * g + 4 * lh) = hv[g];
             ev_lds_barrier();
             // ================= phase 2: acc2 += W2[64 channels of this wave][chunk] . h, K = 128 = 16 k-groups =================
-            const unsigned b0 = (unsigned)((wave * 2) * KG2 + hc * (HC / 8)) * 1024u, b1o = (unsigned)KG2 * 1024u;
             f32x4 B0 = *(const f32x4*)(hrow), B1;
-            auto mma2 = [&](const f32x4 (&a)[2], const f32x4& b) {
+            auto mma2 = [&](const f32x4& a0, const f32x4& a1, const f32x4& b) {
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) {
-                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s4], b[s4], acc2[0][0], 0, 0, 0);
-                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][s4], b[s4], acc2[1][0], 0, 0, 0);
+                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], b[s4], acc2[0][0], 0, 0, 0);
+                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], b[s4], acc2[1][0], 0, 0, 0);
                 }
             };
-            auto ldQ = [&](f32x4 (&dst)[2], int kg) {
-                dst[0] = ev_bload4(rW2, wlane, b0 + (unsigned)kg * 1024u);
-                dst[1] = ev_bload4(rW2, wlane, b0 + b1o + (unsigned)kg * 1024u);
-            };
+#define EV_P2_STEP(FA, FB, BC, BN_, I, RA, RB)                                                   \
+            BN_ = *(const f32x4*)(hrow + ((kb + (I) + 1) & 15) * 8);                              \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            mma2(FA, FB, BC);                                                                    \
+            __builtin_amdgcn_sched_barrier(0);                                                   \
+            FA = RA; FB = RB;
 #pragma unroll 1
-            for (int kg = 0; kg < HC / 8; kg += 4) {
-                const bool more = kg + 4 < HC / 8;
-                B1 = *(const f32x4*)(hrow + (kg + 1) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                mma2(Q0, B0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) ldQ(Q0, kg + 4);
-                B0 = *(const f32x4*)(hrow + (kg + 2) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                mma2(Q1, B1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) ldQ(Q1, kg + 5);
-                B1 = *(const f32x4*)(hrow + (kg + 3) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                mma2(Q2, B0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) ldQ(Q2, kg + 6);
-                if (more) B0 = *(const f32x4*)(hrow + (kg + 4) * 8);
-                __builtin_amdgcn_sched_barrier(0);
-                mma2(Q3, B1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more) ldQ(Q3, kg + 7);
+            for (int kb = 0; kb < 12; kb += 4) {
+                EV_P2_STEP(F0, F1, B0, B1, 0, ldQ(hc, kb + 4, 0), ldQ(hc, kb + 4, 1)) EV_P2_STEP(F2, F3, B1, B0, 1, ldQ(hc, kb + 5, 0), ldQ(hc, kb + 5, 1))
+                EV_P2_STEP(F4, F5, B0, B1, 2, ldQ(hc, kb + 6, 0), ldQ(hc, kb + 6, 1)) EV_P2_STEP(F6, F7, B1, B0, 3, ldQ(hc, kb + 7, 0), ldQ(hc, kb + 7, 1))
             }
+            {   // last four k-groups: the registers go back to phase 1 of the next chunk
+                constexpr int kb = 12;
+                EV_P2_STEP(F0, F1, B0, B1, 0, ldP(htn, 0), ldP(htn, 1)) EV_P2_STEP(F2, F3, B1, B0, 1, ldP(htn, 2), ldP(htn, 3))
+                EV_P2_STEP(F4, F5, B0, B1, 2, ldP(htn, 4), ldP(htn, 5)) EV_P2_STEP(F6, F7, B1, B0, 3, ldP(htn, 6), ldP(htn, 7))
+            }
+#undef EV_P2_STEP
         }
     }
     if constexpr (MODE == 0) {
