@@ -107,6 +107,7 @@ struct ev_handle {
     // small per-stage scratch arenas (denoiser, text encoder): grown on demand, ordered against their last user's stream
     struct Scratch { char* p = nullptr; size_t bytes = 0; hipStream_t last = nullptr; bool last_valid = false; };
     Scratch dn_ws, enc_ws;
+    float* zeros = nullptr;     // 4096 zero floats (stand-in bias for the fused kernels' unconditional loads)
     int max_steps = 64;         // Euler steps the time-grid buffers of the workspace are planned for (grows on demand)
     int* bad_ids_host = nullptr; int* bad_ids_dev = nullptr;   // mapped host word: count of out-of-range token ids seen by ev_text_encoder
     // workspace
@@ -657,7 +658,13 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
     p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T; p.scale = 1.f;
     p.R = R; p.ldr = 256; p.rowmask = rowmask; p.mask2 = (mode == 0 && rowmask) ? 1 : 0;
     mp.X = X; mp.ldx = 256; mp.ln_g = ln_g; mp.ln_b = ln_b; mp.ln_eps = 1e-5f;
-    mp.W1 = L1.W; mp.b1 = L1.bias; mp.M1 = L1.Mpad; mp.alpha = alpha; mp.binv = binv; mp.W2 = L2 ? L2->W : nullptr;
+    if (!L1.bias && !h->zeros) {   // a layer without bias reads zeros: the kernel's bias loads are unconditional
+        HIPCHK(h, hipMalloc((void**)&h->zeros, 4096 * sizeof(float)));
+        HIPCHK(h, hipMemsetAsync(h->zeros, 0, 4096 * sizeof(float), h->stream));
+        h->owned.push_back(h->zeros);
+    }
+    if (L1.Mpad > 4096) return fail(h, "launch_mlp: hidden width %d > 4096", L1.Mpad);
+    mp.W1 = L1.W; mp.b1 = L1.bias ? L1.bias : h->zeros; mp.M1 = L1.Mpad; mp.alpha = alpha; mp.binv = binv; mp.W2 = L2 ? L2->W : nullptr;
     if (L1.Cin != 256 || L1.Kpad != 256 || L1.ntaps != 1 || (L1.Mpad % 128) || L1.Cout != L1.Mpad || (ldy & 3))
         return fail(h, "launch_mlp: first linear must be 256 -> multiple of 128 (got %d -> %d)", L1.Cin, L1.Cout);
     if (mode == 0 && (!L2 || L2->Cout != 256 || L2->Mpad != 256 || L2->Cin != L1.Cout || L2->Kpad != L1.Mpad || L2->ntaps != 1 || !L2->bias || !alpha || !binv))

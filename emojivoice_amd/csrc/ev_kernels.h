@@ -1246,19 +1246,34 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
     const float* xrow = Xs + li * XLD + 4 * lh;
     const float* hrow = Hs + li * HLD + 4 * lh;
 
+    // Per-channel vectors of the hidden width (bias, SnakeBeta alpha / 1/beta) are requested one phase before their use, as
+    // part of the same counted load stream: fetched at the point of use they put one exposed L2 round trip (and a vmcnt(0) that
+    // drained the fragment ring) into every chunk — twice.  mp.b1 always points at readable memory (zeros when the layer has no bias).
+    const __amdgpu_buffer_rsrc_t rB1 = ev_rsrc(mp.b1), rSa = ev_rsrc(MODE == 0 ? mp.alpha : mp.b1), rSb = ev_rsrc(MODE == 0 ? mp.binv : mp.b1);
+    const unsigned coff = (unsigned)(4 * lh) * 4u;     // C/D register 4g+e of a 32-channel tile is channel 8g + 4*half + e
+    f32x4 bq[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB1, coff + (unsigned)(wave * 32 + 8 * g) * 4u, 0);
+
     for (int hc = 0; hc < nchunk; ++hc) {
         const int ht = hc * 4 + wave;                  // this wave's 32 hidden (MODE 1: output) channels of the chunk
         const int htn = hc + 1 < nchunk ? ht + 4 : wave;   // next chunk's tile (after the last chunk: a harmless re-read)
         // ================= phase 1: acc1 = W1[ht] . LN(x) + b1, K = 256 = 32 k-groups =================
         f32x16 acc1;
-        {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc1[4 * g + e] = bq[g][e];
+        f32x4 sa[4], sb[4];
+        if constexpr (MODE == 0) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-                if (mp.b1) bq = *(const f32x4*)(mp.b1 + ht * 32 + 8 * g + 4 * lh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc1[4 * g + e] = bq[e];
+                sa[g] = ev_bload4(rSa, coff + (unsigned)(ht * 32 + 8 * g) * 4u, 0);
+                sb[g] = ev_bload4(rSb, coff + (unsigned)(ht * 32 + 8 * g) * 4u, 0);
             }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB1, coff + (unsigned)(htn * 32 + 8 * g) * 4u, 0);   // next chunk's bias
         }
         {
             f32x4 B0 = *(const f32x4*)(xrow), B1;
@@ -1307,10 +1322,11 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
             f32x4 hv[4];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 sa = *(const f32x4*)(mp.alpha + ht * 32 + 8 * g + 4 * lh), sb = *(const f32x4*)(mp.binv + ht * 32 + 8 * g + 4 * lh);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { const float v = acc1[4 * g + e]; hv[g][e] = fmaf(sb[e], ev_sin2(v * sa[e]), v); }
+                for (int e = 0; e < 4; ++e) { const float v = acc1[4 * g + e]; hv[g][e] = fmaf(sb[g][e], ev_sin2(v * sa[g][e]), v); }
             }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB1, coff + (unsigned)(htn * 32 + 8 * g) * 4u, 0);   // next chunk's bias, under phase 2
             ev_lds_barrier();        // every wave is done reading the previous chunk's Hs (its phase 2)
 #pragma unroll
             for (int g = 0; g < 4; ++g) *(f32x4*)(Hs + li * HLD + wave * 32 + 8 * g + 4 * lh) = hv[g];
