@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libemojivoice_hip.so")
+LIB_PATH = os.environ.get("EV_LIB_PATH") or os.path.join(_HERE, "lib", "libemojivoice_hip.so")   # EV_LIB_PATH: A/B builds of the same ABI
 CSRC = os.path.join(_HERE, "csrc")
 
 EXPORTS = [

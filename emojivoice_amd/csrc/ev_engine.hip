@@ -367,7 +367,7 @@ inline bool lean_ok(const ConvParams& p) {
     return (p.act == ACT_NONE || p.act == ACT_LRELU || (p.act == ACT_SNAKE && (((size_t)p.act_a | (size_t)p.act_b) & 15) == 0)) &&
            ((!p.mask1 && !p.mask2) || (p.rowmask && p.mmul == 1 && !(p.mask2 && lean_acc(p)))) && p.scale == 1.f &&
            !p.Y2 && p.osplit_log2 >= 31 && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (!p.R || (p.ldr & 3) == 0) &&
-           (!p.bias || ((size_t)p.bias & 15) == 0) && !(p.dbg & 4);
+           (!p.bias || ((size_t)p.bias & 15) == 0) && !(p.dbg & 4) && p.S >= 4;   // (lean row walk: two wraps per 8-row pass)
 }
 template <int BM, int BN, int WM, int WN, bool PF = false>
 void launch_cfg(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {

@@ -315,29 +315,28 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     float rmk[NP];                                    // frame-mask values (mask1: before + R, mask2: after), one per row
     const bool mk = p.mask1 || p.mask2;
     const __amdgpu_buffer_rsrc_t rM = ev_rsrc(p.rowmask);
-    int tt = t, nn = n0l;
+    // Every load of the walk is UNCONDITIONAL (a load under a branch makes hipcc stop counting vmcnt and drain it at the next
+    // use): a launch without residual / mask / running sum reads — and ignores — the first bytes of Y instead, and rows outside
+    // the tensor read offset 0.  Rows that are stored always get their real operands.  (Measured as an in-run A/B of two builds
+    // on one box: 0.6 % on the config-2 vocoder; box-to-box spread is larger than that.)
+    const __amdgpu_buffer_rsrc_t rRe = has_r ? rR : rY, rMe = mk ? rM : rY;
+    const bool use_acc = ACC && p.accum;
+    int nn = n0l;
     unsigned ro = roff, ao = yoff;
-    auto issue_one = [&](int q) {                      // next row of the walk (tt / nn / ro / ao advance with it) into slot q
-        const bool ok = co_ok && tt >= 0 && tt < p.T && nn < p.nrows && nn >= win_lo && nn < win_hi;
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        rr[q] = z;
-        if (ok && has_r) rr[q] = ev_bload4(rR, ro, 0);
-        rmk[q] = 1.f;
-        if (ok && mk) rmk[q] = ev_bload1(rM, (unsigned)nn * 4u, 0);
+    auto issue_one = [&](int q) {                      // next row of the walk (nn / ro / ao advance with it) into slot q
+        const bool inr = co_ok && nn >= 0 && nn < p.nrows;
+        rr[q] = ev_bload4(rRe, (has_r && inr) ? ro : 0u, 0);
+        rmk[q] = ev_bload1(rMe, (mk && inr) ? (unsigned)nn * 4u : 0u, 0);
         if constexpr (ACC) {
-            ra[q] = z;
-            if (ok && p.accum) ra[q] = ev_bload4(rY, ao, 0);
+            ra[q] = ev_bload4(rY, (use_acc && inr) ? ao : 0u, 0);
             ao += ystep;
         }
-        tt += RPP; while (tt >= p.S - p.P) tt -= p.S;   // (more than one wrap when an utterance is shorter than a pass: S < RPP)
         nn += RPP;
         ro += rstep;
     };
-    const bool pre = has_r || mk || (ACC && p.accum);
-    if (pre) {
+    const int lim = p.S - p.P;                        // t walks in [-P, S - P); S >= 4 (host: lean_ok), so two conditional wraps cover RPP <= 8
 #pragma unroll
-        for (int q = 0; q < NP; ++q) issue_one(q);
-    }
+    for (int q = 0; q < NP; ++q) issue_one(q);
     ev_lds_barrier();                                 // every wave is done reading the X tile: LDS can be reused
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -367,7 +366,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
             if (has_r) v += rr[q];
             if (p.mask2) v *= rmk[q];
             if constexpr (ACC) {
-                v += ra[q];
+                if (use_acc) v += ra[q];
                 if (p.div3) { v[0] = ev_div3(v[0]); v[1] = ev_div3(v[1]); v[2] = ev_div3(v[2]); v[3] = ev_div3(v[3]); }
                 if (p.act2_lrelu) {
                     v[0] = fmaxf(v[0], v[0] * p.act2_slope); v[1] = fmaxf(v[1], v[1] * p.act2_slope);
@@ -375,8 +374,8 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
                 }
             }
             if (ok) ev_bstore4(rY, yoff, v);
-            if (pre && j + 1 < TN) issue_one(q);      // slot q is free: request the same row of the next slab
-            t += RPP; while (t >= p.S - p.P) t -= p.S;
+            if (j + 1 < TN) issue_one(q);             // slot q is free: request the same row of the next slab
+            t += RPP; t -= (t >= lim) ? p.S : 0; t -= (t >= lim) ? p.S : 0;
             yoff += ystep;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next slab overwrites Es
