@@ -1413,6 +1413,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float mrun = -1e30f, lrun = 0.f;
+    const bool wave_active = __builtin_amdgcn_readfirstlane(q0) < p.T;
 
     const int nkt = (p.T + 31) / 32;
     // K/V tiles are staged through registers one tile ahead: the global loads of tile kt+1 fly while tile kt is being
@@ -1444,6 +1445,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         if (tid < 32) Ms[tid] = mk;
         __syncthreads();
         if (kt + 1 < nkt) kv_load(kt + 1);
+        // a wave whose 32 queries all lie beyond the utterance (T = 516 = 4 x 128 + 4: three of the four waves of every fifth
+        // workgroup; 15-25 % of all waves at the benchmark shapes) only helps staging the K / V tiles
+        if (!wave_active) continue;
         // S^T[key][q] = sum_d K[key][d] * Q[q][d]
         f32x16 s;
 #pragma unroll
