@@ -281,6 +281,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run CFM and HiFi-GAN of each batch back to back on one stream")
     ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--plain", action="store_true", help="profiling aid: warm-up + K serial steps and nothing else (no roofline / CPU / PCIe legs), "
+                    "so that a rocprofv3 --pmc pass sees exactly (W + K) x launches_per_step conv launches")
     args = ap.parse_args()
 
     from emojivoice_amd import dist as D
@@ -326,6 +328,13 @@ def main():
                 full = D.all_gather_waveforms(wav, B * world)
         return full, wav, mel
 
+    if args.plain:
+        for i in range(args.warmup + args.steps):
+            step_local()
+            torch.cuda.synchronize()
+            log(f"[bench] plain step {i + 1}/{args.warmup + args.steps}")
+        close_models(model, voc)
+        return
     log(f"[bench] rank {rank}/{world}: weights loaded, B={B} T={T}; warmup {args.warmup} ...")
     for _ in range(args.warmup):
         tw = time.perf_counter()
