@@ -225,11 +225,20 @@ def run_config5(args, device):
     g = torch.Generator().manual_seed(4321)
     emojis = list(EMOJI_MAPPING.keys()) + ["\U0001F60A"]
     n_utt = args.utterances
-    nwords = torch.randint(2, 40, (n_utt,), generator=g).tolist()
+    # utterance lengths T ~ U{86..860} mel frames (1-10 s).  Lengths come out of the duration predictor, so the
+    # text length is chosen per utterance from a calibration of frames per token on a probe sentence.
+    probe = " ".join(_WORDS[:40])
+    fpt = float(tts.respond(probe + " " + emojis[0])["mel_lengths"][0]) / (2 * len(S.table_front_end(probe)) + 1)
+    targets = torch.randint(86, 861, (n_utt,), generator=g).tolist()
     resp = []
-    for i, nw in enumerate(nwords):
-        ws = [_WORDS[int(k)] for k in torch.randint(0, len(_WORDS), (nw,), generator=g)]
-        resp.append(" ".join(ws) + " " + emojis[i % len(emojis)])
+    for i, tgt in enumerate(targets):
+        n_tok = max(4, int(round((tgt / fpt - 1) / 2)))
+        words, n = [], 0
+        while n < n_tok:
+            w = _WORDS[int(torch.randint(0, len(_WORDS), (1,), generator=g))]
+            words.append(w)
+            n += len(w) + 1
+        resp.append(" ".join(words)[:n_tok] + " " + emojis[i % len(emojis)])
     model.warmup()
     voc.warmup()
     tts.respond("warm up " + emojis[0])
@@ -251,7 +260,7 @@ def run_config5(args, device):
         "config": {"workload": f"config5: feel_me.py TTS loop, {n_utt} utterances B=1, {min(frames)}-{max(frames)} mel frames, 11 emoji voices + default, "
                                "length_scale 0.8, 10 Euler steps, temperature 0.667, HiFi-GAN + clamp + denoiser, text on host -> waveform on host"},
         "p50_ms": round(p50, 2), "p99_ms": round(p99, 2), "mean_ms": round(float(lat.mean()) * 1e3, 2), "max_ms": round(float(lat.max()) * 1e3, 2),
-        "mean_audio_s": round(float(audio.mean()), 2), "mean_rtf": round(float((lat / audio).mean()), 5),
+        "mean_frames": round(float(np.mean(frames)), 1), "mean_audio_s": round(float(audio.mean()), 2), "mean_rtf": round(float((lat / audio).mean()), 5),
         "x_realtime_stream": round(float(audio.sum() / lat.sum()), 1)}), flush=True)
     close_models(model, voc)
 
