@@ -227,18 +227,29 @@ def run_config5(args, device):
     n_utt = args.utterances
     # utterance lengths T ~ U{86..860} mel frames (1-10 s).  Lengths come out of the duration predictor, so the
     # text length is chosen per utterance from a calibration of frames per token on a probe sentence.
-    probe = " ".join(_WORDS[:40])
-    fpt = float(tts.respond(probe + " " + emojis[0])["mel_lengths"][0]) / (2 * len(S.table_front_end(probe)) + 1)
-    targets = torch.randint(86, 861, (n_utt,), generator=g).tolist()
-    resp = []
-    for i, tgt in enumerate(targets):
-        n_tok = max(4, int(round((tgt / fpt - 1) / 2)))
+    def make_text(n_chars):
         words, n = [], 0
-        while n < n_tok:
+        while n < n_chars:
             w = _WORDS[int(torch.randint(0, len(_WORDS), (1,), generator=g))]
             words.append(w)
             n += len(w) + 1
-        resp.append(" ".join(words)[:n_tok] + " " + emojis[i % len(emojis)])
+        return " ".join(words)[:n_chars]
+
+    # utterance lengths T ~ U{86..860} mel frames (1-10 s).  A length comes out of the duration predictor, so each
+    # utterance's text (a prefix of its own seeded word stream) is trimmed in an UNTIMED pre-pass until its mel length is within
+    # 10 % of its target; the timed loop below then replays exactly those texts.
+    targets = torch.randint(86, 861, (n_utt,), generator=g).tolist()
+    resp = []
+    for i, tgt in enumerate(targets):
+        stream_txt, n_chars = make_text(1500), max(4, tgt // 3)
+        for _ in range(6):
+            f = float(tts.respond(stream_txt[:n_chars] + " " + emojis[i % len(emojis)])["mel_lengths"][0])
+            if abs(f - tgt) <= 0.1 * tgt:
+                break
+            n_chars = int(min(1500, max(4, round(n_chars * tgt / max(f, 1.0)))))
+        resp.append(stream_txt[:n_chars] + " " + emojis[i % len(emojis)])
+        if i % 16 == 15:
+            log(f"[bench] config5: calibrated {i + 1}/{n_utt} utterance lengths")
     model.warmup()
     voc.warmup()
     tts.respond("warm up " + emojis[0])
