@@ -423,7 +423,7 @@ def main():
         per_gpu = value / world
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "conv_gemm_kernel + resblock_pair_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                    "kernel": "conv_gemm_kernel + resblock_pair_kernel + ln_mlp_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
                     "schedule": "serial pass (one stream, stages back to back, see serial_ms_per_step); `value` is the two-stream pipeline",
                     "launches_per_step": int(conv_n), "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
                     "alg_gflop_per_launch": round(conv_fl / max(conv_n, 1) / 1e9, 3),
