@@ -22,7 +22,7 @@ EXPORTS = [
     "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder", "ev_load_text_encoder", "ev_text_encoder",
     "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read",
-    "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention",
+    "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention", "ev_op_ln_mlp",
 ]
 
 
@@ -93,6 +93,7 @@ def load_library() -> C.CDLL:
     lib.ev_op_groupnorm_mish.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ev_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.ev_op_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.ev_op_ln_mlp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     for n in EXPORTS:
         getattr(lib, n)  # raises AttributeError if a declared symbol is not exported
     _lib = lib
@@ -314,6 +315,24 @@ class Engine:
         y = torch.empty_like(x)
         self._check(self.lib.ev_op_layernorm(self.h, x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rows, Cc, y.data_ptr(),
                                              _stream_ptr()), "ev_op_layernorm")
+        return y
+
+    def op_ln_mlp(self, x, ln_g, ln_b, w1, b1, alpha=None, beta=None, w2=None, b2=None, rowmask=None):
+        """ln_mlp_kernel on (rows, 256): with w2 -> x + W2.SnakeBeta(W1.LN(x)+b1)+b2 (* rowmask); without -> W1.LN(x) (+ b1)."""
+        x, ln_g, ln_b = self._f32(x), self._f32(ln_g), self._f32(ln_b)
+        rows = x.shape[0]
+        M1 = w1.shape[0]
+        host = lambda t: None if t is None else np.ascontiguousarray(t.detach().cpu().float().numpy())   # noqa: E731
+        w1h, b1h, w2h, b2h = host(w1), host(b1), host(w2), host(b2)
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)   # noqa: E731
+        mode = 0 if w2 is not None else 1
+        a_exp = self._f32(torch.exp(alpha.float()).to(x.device)) if alpha is not None else None
+        b_inv = self._f32((1.0 / (torch.exp(beta.float()) + 0.000000001)).to(x.device)) if beta is not None else None
+        rm = self._f32(rowmask) if rowmask is not None else None
+        y = torch.empty((rows, 256 if mode == 0 else M1), dtype=torch.float32, device=x.device)
+        dp = lambda t: None if t is None else t.data_ptr()   # noqa: E731
+        self._check(self.lib.ev_op_ln_mlp(self.h, x.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(), ptr(w1h), ptr(b1h), dp(a_exp), dp(b_inv),
+                                          ptr(w2h), ptr(b2h), dp(rm), rows, M1, mode, y.data_ptr(), _stream_ptr()), "ev_op_ln_mlp")
         return y
 
     def op_attention(self, qkv, lengths, heads=2):

@@ -670,6 +670,7 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
     if (mode == 0 && (!L2 || L2->Cout != 256 || L2->Mpad != 256 || L2->Cin != L1.Cout || L2->Kpad != L1.Mpad || L2->ntaps != 1 || !L2->bias || !alpha || !binv))
         return fail(h, "launch_mlp: second linear must be %d -> 256 with bias", L1.Cout);
     if ((double)g.nrows * std::max(ldy, 256) * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
+    if (g.S < 4 && g.nrows > 1) return fail(h, "launch_mlp: utterance stride %d < 4 rows is not supported by the lean row walk", g.S);
     const int ntiles = (g.nrows + 31) / 32;
     const size_t smem = (size_t)(32 * 260 + 4 * 32 * 36) * sizeof(float);
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -1820,6 +1821,36 @@ int ev_op_layernorm(ev_handle* h, const float* d_x, const float* d_gamma, const 
     if (C != 256) return fail(h, "layernorm op: C=256 only");
     Geom g{rows, rows, 0, rows};
     return launch_ln(h, d_x, C, d_y, C, d_gamma, d_beta, g);
+}
+
+// LayerNorm(256) -> Linear(256 -> M1) [-> SnakeBeta -> Linear(M1 -> 256) + residual x, * mask]: ln_mlp_kernel on (rows, 256) rows
+int ev_op_ln_mlp(ev_handle* h, const float* d_x, const float* d_ln_g, const float* d_ln_b, const float* w1, const float* b1,
+                 const float* d_alpha_exp, const float* d_beta_inv, const float* w2, const float* b2, const float* d_rowmask,
+                 int rows, int M1, int mode, float* d_y, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->stream = (hipStream_t)stream;
+    if (rows <= 0 || (M1 % 128) || !d_x || !w1 || !d_y || (mode == 0 && (!w2 || !b2 || !b1 || !d_alpha_exp || !d_beta_inv))) return fail(h, "ev_op_ln_mlp: bad arguments");
+    size_t owned0 = h->owned.size();
+    ConvLayer L1, L2;
+    HostTensor t1, tb1, t2, tb2;
+    t1.p = w1; t1.ndim = 2; t1.shape[0] = M1; t1.shape[1] = 256;
+    tb1.p = b1; tb1.ndim = 1; tb1.shape[0] = M1;
+    int rc = pack_linear_stack(h, L1, {&t1}, b1 ? std::vector<const HostTensor*>{&tb1} : std::vector<const HostTensor*>{});
+    if (!rc && mode == 0) {
+        t2.p = w2; t2.ndim = 2; t2.shape[0] = 256; t2.shape[1] = M1;
+        tb2.p = b2; tb2.ndim = 1; tb2.shape[0] = 256;
+        rc = pack_linear_stack(h, L2, {&t2}, {&tb2});
+    }
+    Geom g{rows, rows, 0, rows};
+    if (!rc) rc = launch_mlp(h, mode, d_x, d_ln_g, d_ln_b, L1, mode == 0 ? &L2 : nullptr, d_alpha_exp, d_beta_inv, mode == 0 ? d_x : nullptr,
+                             mode == 0 ? d_rowmask : nullptr, d_y, mode == 0 ? 256 : M1, g);
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, "sync failed");
+    while (h->owned.size() > owned0) {
+        if (h->owned.back() == (void*)h->zeros) break;      // (the handle's zero buffer may have been created by this call: keep it)
+        hipFree(h->owned.back()); h->owned.pop_back();
+    }
+    return rc;
 }
 
 int ev_op_attention(ev_handle* h, const float* d_qkv, const int32_t* d_lengths, int B, int T, int heads, float* d_out, void* stream) {

@@ -150,6 +150,12 @@ int ev_op_groupnorm_mish(ev_handle *h, const float *d_x /*(B,C,T)*/, const float
                          const int32_t *d_lengths, int B, int C, int T, int groups, float *d_y, void *stream);
 int ev_op_layernorm(ev_handle *h, const float *d_x /*(rows,C)*/, const float *d_gamma, const float *d_beta, int rows,
                     int C, float *d_y, void *stream);
+/* ln_mlp_kernel: y = x + W2.SnakeBeta(W1.LN(x) + b1) + b2, rows * mask (mode 0; transformer.py:300-316) or y = W1.LN(x) [+ b1]
+ * (mode 1: the QKV projection, y is (rows, M1)); x (rows, 256); alpha_exp = exp(alpha), beta_inv = 1/(exp(beta)+1e-9) (M1);
+ * w1 (M1, 256) and w2 (256, M1) are HOST pointers; M1 a multiple of 128; rowmask (rows) or NULL. */
+int ev_op_ln_mlp(ev_handle *h, const float *d_x, const float *d_ln_g, const float *d_ln_b, const float *w1, const float *b1,
+                 const float *d_alpha_exp, const float *d_beta_inv, const float *w2, const float *b2, const float *d_rowmask,
+                 int rows, int M1, int mode, float *d_y, void *stream);
 int ev_op_attention(ev_handle *h, const float *d_qkv /*(B,T,3*heads*64)*/, const int32_t *d_lengths, int B, int T,
                     int heads, float *d_out /*(B,T,heads*64)*/, void *stream);
 

@@ -289,3 +289,95 @@ def test_unsupported_head_count_is_refused():
 
     with pytest.raises(EvLibraryError):
         Engine(0, spk_emb_dim=64, heads=4)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# callers either side of the path
+# ---------------------------------------------------------------------------------------------------------------------
+def test_cli_batched_and_phoneme_input(tmp_path):
+    """`--batched` (cli.py:277-317: padded id batch, one speaker per line or the default) and `--phonemes` / `--file_phonemes`
+    (IPA text through the reference's symbol table) produce one wav per utterance with wav_len == 256 * mel_len; the batched
+    run equals the same utterances synthesised as that batch through the Python surface."""
+    import wave
+
+    from emojivoice_amd import cli
+    from emojivoice_amd import text as T
+
+    lines = ["həlˈoʊ wˈɜːld|12", "ðə kwˈɪk bɹˈaʊn fˈɑːks.|107", "nˈaɪs"]
+    f = tmp_path / "utts.txt"
+    f.write_text("\n".join(lines), encoding="utf-8")
+    out = tmp_path / "out"
+    torch.manual_seed(31)
+    cli.cli(["--synthetic", "--file", str(f), "--file_phonemes", "--batched", "--batch_size", "3", "--spk", "5", "--steps", "4",
+             "--output_folder", str(out)])
+    wavs = sorted(out.glob("*.wav"))
+    assert [w.name for w in wavs] == ["utterance_001_speaker_012.wav", "utterance_002_speaker_107.wav", "utterance_003_speaker_005.wav"]
+    for w, ln in zip(wavs, lines):
+        mel = np.load(str(w)[:-4] + ".npy")
+        with wave.open(str(w)) as wf:
+            assert (wf.getframerate(), wf.getsampwidth()) == (22050, 3) and wf.getnframes() == 256 * mel.shape[1]
+    ids0 = T.process_phonemes(lines[0].split("|")[0])
+    assert ids0[0] == 0 and ids0[1] == T._symbol_to_id["h"] and len(ids0) == 2 * len("həlˈoʊ wˈɜːld") + 1
+    out2 = tmp_path / "out2"
+    cli.cli(["--synthetic", "--phonemes", "nˈaɪs", "--emoji-text", "ok \U0001F914", "--steps", "4", "--output_folder", str(out2)])
+    assert [w.name for w in sorted(out2.glob("*.wav"))] == ["utterance_001_speaker_017.wav"]
+
+
+def test_long_utterance_vs_oracle(model, vocoder, sds):
+    """A 17-s utterance (T = 1500: 47 key tiles in attention, GroupNorm slabs beyond the register-resident path, 3 M samples of
+    audio) next to a short one."""
+    sd, voc_sd = sds
+    g = torch.Generator().manual_seed(1500)
+    B, Tp = 2, 1500
+    mu = torch.randn(B, 80, Tp, generator=g)
+    z = torch.randn(B, 80, Tp, generator=g)
+    lengths = torch.tensor([1500, 333])
+    mask = O.sequence_mask(lengths, Tp).unsqueeze(1).float()
+    spk = sd["spk_emb.weight"][torch.tensor([22, 66])]
+    ref = O.cfm_decode(sd, mu * mask, mask, 2, 0.667, spk, z=z)
+    dec, mel = model.decode((mu * mask).cuda(), lengths.cuda(), 2, 0.667, spk.cuda(), z=z.cuda())
+    assert _linf(dec, ref) <= MEL_GATE / 2
+    ref_wav = O.hifigan_forward(voc_sd, O.denormalize(ref[:1], sd["mel_mean"], sd["mel_std"]), W.HIFIGAN_V1)
+    wav = vocoder(mel[:1])
+    assert wav.shape == (1, 1, 256 * Tp) and _rms(wav, ref_wav) <= WAV_RMS_GATE / 10
+
+
+def test_synthesise_sharded_single_rank_equals_synthesise(model, vocoder):
+    """dist.synthesise_sharded with one rank (no process group) is synthesise + to_waveform's clamp for the whole batch."""
+    from emojivoice_amd import dist as D
+
+    g = torch.Generator().manual_seed(77)
+    ids = torch.randint(1, 178, (3, 21), generator=g).cuda()
+    xl = torch.tensor([21, 9, 15]).cuda()
+    spks = torch.tensor([12, 107, 0]).cuda()
+    torch.manual_seed(5)
+    out = D.synthesise_sharded(model, vocoder, ids, xl, 3, 0.667, spks, 0.8)
+    torch.manual_seed(5)
+    ref = model.synthesise(ids, xl, 3, 0.667, spks, 0.8)
+    assert torch.equal(out["mel_lengths"].cpu(), ref["mel_lengths"].cpu()) and out["ranks"] == 1
+    n = ref["mel"].shape[-1]
+    assert torch.equal(out["mel"][:, :, :n], ref["mel"])
+    assert out["wav"].shape == (3, 1, 256 * out["Tp"]) and bool(torch.isfinite(out["wav"]).all())
+
+
+def test_rccl_backend_single_rank_collectives():
+    """The N > 1 path uses torch.distributed's "nccl" backend (= RCCL on ROCm).  Only one GPU is visible here, so this checks
+    what can be checked: the backend initialises on this box and the two collectives of the path (MAX all-reduce of the padded
+    length, all_gather_into_tensor of the waveform block) run on device tensors in a one-rank group."""
+    import os
+    import subprocess
+    import sys
+
+    code = r'''
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29571", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+t = torch.tensor([515], dtype=torch.int64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+w = torch.arange(2 * 1024, dtype=torch.float32, device="cuda").reshape(2, 1, 1024); out = torch.empty_like(w)
+dist.all_gather_into_tensor(out, w); dist.barrier(); torch.cuda.synchronize()
+assert int(t) == 515 and torch.equal(out, w)
+dist.destroy_process_group(); print("rccl ok")
+'''
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ))
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
