@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         for (int g = 0; g < 8; ++g) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (ok) v = *(const f32x4*)(Qp + (rowbase + tq) * p.ld + 8 * g + 4 * lh);
-            qf[g] = v * p.scale;
+            qf[g] = v * (p.scale * 1.44269504088896340736f);   // scores in the log2 domain: exp(x) = exp2(x * log2 e), one v_exp_f32 each
         }
     }
     f32x16 o0, o1;
@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         // publish the prefetched 32 keys x 64 dims of K and V (rows past T are zero, masked below)
         *(f32x4*)(Ks + sr * ATT_LDK + sc) = k0; *(f32x4*)(Ks + sr * ATT_LDK + sc + 4) = k1;
         *(f32x4*)(Vs + sr * ATT_LDK + sc) = v0; *(f32x4*)(Vs + sr * ATT_LDK + sc + 4) = v1;
-        if (tid < 32) Ms[tid] = mk;
+        if (tid < 32) Ms[tid] = mk * 1.44269504088896340736f;
         __syncthreads();
         if (kt + 1 < nkt) kv_load(kt + 1);
         // a wave whose 32 queries all lie beyond the utterance (T = 516 = 4 x 128 + 4: three of the four waves of every fifth
@@ -1467,10 +1467,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float mnew = fmaxf(mrun, mx);
-        const float alpha = expf(mrun - mnew);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = expf(s[r] - mnew); ps += s[r]; }
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mnew); ps += s[r]; }
         ps += __shfl_xor(ps, 32, 64);
         lrun = lrun * alpha + ps;
         mrun = mnew;
