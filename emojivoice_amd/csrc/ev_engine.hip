@@ -118,7 +118,8 @@ struct ev_handle {
     bool fuse_pairs = true;     // EV_FUSE_PAIRS=0 disables resblock_pair_kernel (A/B runs)
     int fuse128 = 3;            // fuse C=128 pairs up to this kernel size (EV_FUSE128=0/3/7/11)
     bool fuse_mlp = true;       // EV_FUSE_MLP=0: LayerNorm / QKV / feed-forward of the transformer blocks as separate launches
-    int fuse_mlp_min_tiles = 192;   // EV_FUSE_MLP_MIN=<32-row tiles>: below this the separate (split-K) launches are used
+    int fuse_mlp_min_tiles = 96;    // EV_FUSE_MLP_MIN=<32-row tiles>: below this the separate (split-K) launches are used (measured with
+                                    // tools/fuse_threshold.py at T = 516: batch 4 fused 13.4 / separate 12.1 ms, batch 8 15.1 / 15.2, batch 16 19.7 / 21.6)
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     hipStream_t ws_stream = nullptr; bool ws_stream_valid = false;   // stream of the last call that used the workspace
     float* temb_host[2] = {nullptr, nullptr}; size_t temb_cap[2] = {0, 0}; hipEvent_t temb_ev[2] = {nullptr, nullptr}; int temb_slot = 0;
