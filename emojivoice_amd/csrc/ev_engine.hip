@@ -343,13 +343,15 @@ struct LaunchOpts {
 };
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is sticky per (function, device): issue it only when a launch needs more
-// than any earlier launch of that instantiation asked for (it costs host time on the ~640-launch batch-1 chain).
-template <typename K>
-inline void ensure_dyn_smem(K kernel, size_t smem, int device) {
+// than any earlier launch of THAT kernel asked for (it costs host time on the ~640-launch batch-1 chain).  The kernel is a
+// non-type template parameter, so every instantiation has its own high-water marks (all conv instantiations share one
+// function-pointer TYPE: a type-keyed cache would let one instantiation's grant hide another's request).
+template <auto Kernel>
+inline void ensure_dyn_smem(size_t smem, int device) {
     static std::atomic<int> granted[16];
     const int d = device & 15;
     if (smem <= 65536 || (int)smem <= granted[d].load(std::memory_order_relaxed)) return;
-    hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     int cur = granted[d].load(std::memory_order_relaxed);
     while (cur < (int)smem && !granted[d].compare_exchange_weak(cur, (int)smem, std::memory_order_relaxed)) {}
 }
@@ -390,7 +392,7 @@ void launch_cfg2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4);
     size_t smem = (xs > es ? xs : es) * sizeof(float);
     if (lo.wgs_per_cu > 0) { size_t cap = (size_t)(160 * 1024 / lo.wgs_per_cu) & ~(size_t)255; if (cap > smem) smem = cap; }
-    ensure_dyn_smem(conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>, smem, lo.device);
+    ensure_dyn_smem<conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>>(smem, lo.device);
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
@@ -402,7 +404,7 @@ void launch_sk2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     const size_t xs = 2 * EV_MAX_TAPS + (size_t)(64 + ((lo.halo + 7) & ~7)) * (32 * kbs + 4);
     const size_t red = (size_t)(KS - 1) * 4 * 16 * 64, es = (size_t)4 * 32 * 36;
     size_t smem = std::max(xs, std::max(red, es)) * sizeof(float);
-    ensure_dyn_smem(conv_gemm_sk_kernel<KS, FULL, LEAN>, smem, lo.device);
+    ensure_dyn_smem<conv_gemm_sk_kernel<KS, FULL, LEAN>>(smem, lo.device);
     hipLaunchKernelGGL((conv_gemm_sk_kernel<KS, FULL, LEAN>), dim3(p.mtiles * p.ntiles), dim3(256 * KS), smem, st, p);
 }
 void launch_sk(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {

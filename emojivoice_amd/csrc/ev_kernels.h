@@ -571,7 +571,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
                 const unsigned soff = x_soff(ch);
 #pragma unroll
                 for (int q0 = 0; q0 < XPASS; q0 += XG) {
-                    if (q0 * RPS >= xrows) break;
+                    if (q0 * RPS >= xrows) continue;
                     f32x4 xg[XG];
 #pragma unroll
                     for (int q = 0; q < XG; ++q) {
