@@ -478,6 +478,14 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         const long wg64 = (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64);
         if (!no_sk && (cfg == 6 || cfg == 8) && wg64 <= 192 && (L.Kpad / EV_BK) * L.ntaps >= 8) cfg = 9;
     }
+    {   // A/B override for the stacked sparse-tap layers only (a 3-tap conv over a 1x1 conv): EV_SPARSE_CFG=<cfg>[,<min rows>]
+        static const char* senv = getenv("EV_SPARSE_CFG");
+        if (senv && *senv && L.sparse_taps && L.Cout > 32) {
+            int c = atoi(senv), minrows = 0;
+            if (const char* comma = strchr(senv, ',')) minrows = atoi(comma + 1);
+            if (g.nrows >= minrows) cfg = c;
+        }
+    }
     {   // debugging / test override: EV_FORCE_CFG=<0..3> forces one tile configuration for every conv launch
         static const char* env = getenv("EV_FORCE_CFG");
         if (env && *env) cfg = atoi(env);
