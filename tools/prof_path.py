@@ -37,4 +37,7 @@ if a.what in ("cfm", "both"):
     for _ in range(a.iters + 1):
         dec = m.engine.cfm_decode(mu, lengths, spk, z, a.ode_steps)
     torch.cuda.synchronize()
+for o in (globals().get("voc"), globals().get("m")):       # destroy the native handles while the runtime (and a profiler) is alive
+    if o is not None and getattr(o, "engine", None) is not None:
+        o.engine.close()
 print("done")
