@@ -709,7 +709,16 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
 int launch_attn(ev_handle* h, const float* QKV, int ld, float* O, int ldo, const float* rowmask, const Geom& g, int H) {
     AttnParams p;
     p.QKV = QKV; p.ld = ld; p.O = O; p.ldo = ldo; p.rowmask = rowmask; p.S = g.S; p.P = g.P; p.T = g.T; p.H = H; p.scale = 0.125f;
-    hipLaunchKernelGGL(attention_kernel, dim3((g.T + 127) / 128, H, g.nrows / g.S), dim3(256), 0, h->stream, p);
+    const int nwg = ((g.T + 127) / 128) * H * (g.nrows / g.S), nkt = (g.T + 31) / 32;
+    static const bool no_sk = getenv("EV_NO_ATTN_SK") != nullptr;
+    if (!no_sk && nwg <= 64 && nkt >= 4) {   // far fewer workgroups than CUs: split the key tiles over two wave groups per workgroup
+        constexpr int KS = 2;
+        const size_t gs = (size_t)(2 * 32 * ATT_LDK + 32), mb = (size_t)(KS - 1) * 4 * 34 * 64;
+        const size_t smem = std::max((size_t)KS * gs, mb) * sizeof(float);
+        hipLaunchKernelGGL(attention_sk_kernel<KS>, dim3((g.T + 127) / 128, H, g.nrows / g.S), dim3(256 * KS), smem, h->stream, p);
+    } else {
+        hipLaunchKernelGGL(attention_kernel, dim3((g.T + 127) / 128, H, g.nrows / g.S), dim3(256), 0, h->stream, p);
+    }
     HIPCHK(h, hipGetLastError());
     return 0;
 }

@@ -1501,6 +1501,151 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------
+// attention_sk_kernel: the small-launch build of attention_kernel.  A batch-1 decode has 6-10 workgroups per attention
+// launch, each a serial chain over all 9-17 key tiles (~2.8 us per tile: two barriers, 32 dependent MFMAs for the scores, the
+// softmax, 32 MFMAs for P.V): 27-48 us per launch, 60 launches per decode.  Here a workgroup is 4*KS waves: KS wave groups
+// share the 128 queries and split the key tiles (group g takes tiles g, g + KS, ...), each with its own K / V staging
+// buffers and its own online-softmax state; the KS partial states (m, l, O) are merged through LDS in a fixed order
+// (group 0 <- 1 <- 2 ...: deterministic) before group 0 normalises and stores.  Same products as attention_kernel; only the
+// order in which the key tiles' contributions are combined differs.
+// ---------------------------------------------------------------------------
+template <int KS>
+__global__ __launch_bounds__(256 * KS) void attention_sk_kernel(const AttnParams p) {
+    constexpr int GS = 2 * 32 * ATT_LDK + 32;            // floats per group: K tile, V tile, mask row
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w = wave & 3, gt = tid & 255;
+    float* Ks = smem + grp * GS;
+    float* Vs = Ks + 32 * ATT_LDK;
+    float* Ms = Vs + 32 * ATT_LDK;
+    const int li = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.z, hd = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + w * 32;
+    const size_t rowbase = (size_t)b * p.S + p.P;
+    const int HD = p.H * 64;
+    const float* Qp = p.QKV + hd * 64;
+    const float* Kp = p.QKV + HD + hd * 64;
+    const float* Vp = p.QKV + 2 * HD + hd * 64;
+    f32x4 qf[8];
+    {
+        const int tq = q0 + li;
+        const bool ok = tq < p.T;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (ok) v = *(const f32x4*)(Qp + (rowbase + tq) * p.ld + 8 * g + 4 * lh);
+            qf[g] = v * (p.scale * 1.44269504088896340736f);
+        }
+    }
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float mrun = -1e30f, lrun = 0.f;
+    const bool wave_active = q0 < p.T;
+    const int nkt = (p.T + 31) / 32;
+    const int nit = (nkt + KS - 1) / KS;                  // every group runs the same number of (barrier) iterations
+    const int sr = gt >> 3, sc = (gt & 7) * 8;
+    f32x4 k0, k1, v0, v1;
+    float mk;
+    auto kv_load = [&](int kt) {
+        const int tk = kt * 32 + sr;
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        k0 = z; k1 = z; v0 = z; v1 = z;
+        if (tk < p.T) {
+            const float* kr = Kp + (rowbase + tk) * p.ld + sc;
+            const float* vr = Vp + (rowbase + tk) * p.ld + sc;
+            k0 = *(const f32x4*)kr; k1 = *(const f32x4*)(kr + 4);
+            v0 = *(const f32x4*)vr; v1 = *(const f32x4*)(vr + 4);
+        }
+        const int tm = kt * 32 + (gt & 31);
+        mk = (tm < p.T) ? p.rowmask[rowbase + tm] : -1e30f;
+    };
+    kv_load(grp);                                         // (a tile index beyond nkt loads zeros and a -1e30 mask: never used)
+    for (int it = 0; it < nit; ++it) {
+        const int kt = it * KS + grp;
+        const bool tile_ok = kt < nkt;                    // uniform per wave group
+        __syncthreads();
+        *(f32x4*)(Ks + sr * ATT_LDK + sc) = k0; *(f32x4*)(Ks + sr * ATT_LDK + sc + 4) = k1;
+        *(f32x4*)(Vs + sr * ATT_LDK + sc) = v0; *(f32x4*)(Vs + sr * ATT_LDK + sc + 4) = v1;
+        if (gt < 32) Ms[gt] = mk * 1.44269504088896340736f;
+        __syncthreads();
+        kv_load(kt + KS);
+        if (!wave_active || !tile_ok) continue;
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            f32x4 a = *(const f32x4*)(Ks + li * ATT_LDK + 8 * g + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qf[g][e], s, 0, 0, 0);
+        }
+        float mx = -1e30f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] += Ms[(r & 3) + 8 * (r >> 2) + 4 * lh];
+            mx = fmaxf(mx, s[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mnew); ps += s[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float a0 = Vs[key * ATT_LDK + li];
+            const float a1 = Vs[key * ATT_LDK + 32 + li];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], o1, 0, 0, 0);
+        }
+    }
+    // ---- merge the KS partial states through LDS (aliases the staging buffers), group 0 <- 1 <- 2 ...
+    __syncthreads();
+    float* mb = smem + ((grp > 0 ? grp - 1 : 0) * 4 + w) * (34 * 64);    // [34 values][64 lanes] per (group, query wave)
+    if (grp > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { mb[r * 64 + lane] = o0[r]; mb[(16 + r) * 64 + lane] = o1[r]; }
+        mb[32 * 64 + lane] = mrun; mb[33 * 64 + lane] = lrun;
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int g = 1; g < KS; ++g) {
+        const float* src = smem + ((g - 1) * 4 + w) * (34 * 64);
+        const float m1 = src[32 * 64 + lane], l1 = src[33 * 64 + lane];
+        const float mnew = fmaxf(mrun, m1);
+        const float a0 = __builtin_amdgcn_exp2f(mrun - mnew), a1 = __builtin_amdgcn_exp2f(m1 - mnew);
+        lrun = lrun * a0 + l1 * a1;
+        mrun = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] = o0[r] * a0 + src[r * 64 + lane] * a1;
+            o1[r] = o1[r] * a0 + src[(16 + r) * 64 + lane] * a1;
+        }
+    }
+    const int tq = q0 + li;
+    if (tq < p.T) {
+        const float inv = 1.0f / lrun;
+        float* orow = p.O + (rowbase + tq) * p.ldo + hd * 64;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+            f32x4 c = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+            *(f32x4*)(orow + 8 * g + 4 * lh) = a;
+            *(f32x4*)(orow + 32 + 8 * g + 4 * lh) = c;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Layout / elementwise helpers
 // ---------------------------------------------------------------------------
 // rowmask[n] = 1 if 0 <= t < ceil(len[b] / sub) (sub = 1: level-0 mask; sub = 2: mask[:, :, ::2]), else 0

@@ -1,5 +1,5 @@
 """The kernel A/B switches (tile configuration, two-chunk staging, generic instead of lean epilogue, unfused resblock pairs,
-fused LayerNorm + QKV / feed-forward kernels forced on at a small batch or switched off)
+fused LayerNorm + QKV / feed-forward kernels forced on at a small batch or switched off, split-key attention switched off)
 must not change results: every build accumulates in the same (chunk, tap, k-group) order, so the variants agree with the
 default path to fp32 rounding of the epilogue (bias added before vs after the K loop).  The switches are read once per
 process, hence one child process per variant."""
@@ -33,7 +33,7 @@ torch.save({"mel": mel.cpu(), "wav": wav.cpu()}, sys.argv[1])
 """ % REPO
 
 VARIANTS = [{"EV_KB": "2"}, {"EV_NO_LEAN": "1"}, {"EV_FUSE_PAIRS": "0"}, {"EV_FORCE_CFG": "0"}, {"EV_FORCE_CFG": "5"}, {"EV_FORCE_CFG": "6"},
-            {"EV_FORCE_CFG": "4"}, {"EV_FUSE_MLP_MIN": "1"}, {"EV_FUSE_MLP": "0"}]
+            {"EV_FORCE_CFG": "4"}, {"EV_FUSE_MLP_MIN": "1"}, {"EV_FUSE_MLP": "0"}, {"EV_NO_ATTN_SK": "1"}]
 
 
 def _run(tmp_path, name, extra):
