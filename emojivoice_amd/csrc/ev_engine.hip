@@ -396,25 +396,27 @@ void launch_cfg2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
-// small-launch build (conv_gemm_sk_kernel): 64 x 64 tiles, 16 waves, K split four ways inside the workgroup
-template <bool FULL, int LEAN>
+// small-launch builds (conv_gemm_sk_kernel): 64 x 64 tiles, 16 waves, K split four ways inside the workgroup (TW = 4, KS = 4),
+// or 32 x 32 tiles, 8 waves, K split eight ways (TW = 1, KS = 8) for launches of only a few dozen 64 x 64 tiles
+template <bool FULL, int LEAN, int TW>
 void launch_sk2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
-    constexpr int KS = 4;
+    constexpr int KS = TW == 4 ? 4 : 8, BN = TW == 4 ? 64 : 32;
     const int nchunks = p.Kpad / EV_BK, kbs = nchunks < 8 ? nchunks : 8;
-    const size_t xs = 2 * EV_MAX_TAPS + (size_t)(64 + ((lo.halo + 7) & ~7)) * (32 * kbs + 4);
-    const size_t red = (size_t)(KS - 1) * 4 * 16 * 64, es = (size_t)4 * 32 * 36;
+    const size_t xs = 2 * EV_MAX_TAPS + (size_t)(BN + ((lo.halo + 7) & ~7)) * (32 * kbs + 4);
+    const size_t red = (size_t)(KS - 1) * TW * 16 * 64, es = (size_t)TW * 32 * 36;
     size_t smem = std::max(xs, std::max(red, es)) * sizeof(float);
-    ensure_dyn_smem<conv_gemm_sk_kernel<KS, FULL, LEAN>>(smem, lo.device);
-    hipLaunchKernelGGL((conv_gemm_sk_kernel<KS, FULL, LEAN>), dim3(p.mtiles * p.ntiles), dim3(256 * KS), smem, st, p);
+    ensure_dyn_smem<conv_gemm_sk_kernel<KS, FULL, LEAN, TW>>(smem, lo.device);
+    hipLaunchKernelGGL((conv_gemm_sk_kernel<KS, FULL, LEAN, TW>), dim3(p.mtiles * p.ntiles), dim3(64 * TW * KS), smem, st, p);
 }
+template <int TW>
 void launch_sk(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
     if (!no_lean && lean_ok(p)) {
-        if (p.act == ACT_SNAKE) launch_sk2<false, 2>(p, st, lo);
-        else if (lean_acc(p)) launch_sk2<false, 3>(p, st, lo);
-        else launch_sk2<false, 1>(p, st, lo);
-    } else if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_sk2<false, 0>(p, st, lo);
-    else launch_sk2<true, 0>(p, st, lo);
+        if (p.act == ACT_SNAKE) launch_sk2<false, 2, TW>(p, st, lo);
+        else if (lean_acc(p)) launch_sk2<false, 3, TW>(p, st, lo);
+        else launch_sk2<false, 1, TW>(p, st, lo);
+    } else if (p.act == ACT_NONE || p.act == ACT_LRELU) launch_sk2<false, 0, TW>(p, st, lo);
+    else launch_sk2<true, 0, TW>(p, st, lo);
 }
 
 int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {
@@ -477,6 +479,9 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         static const bool no_sk = getenv("EV_NO_SK") != nullptr;
         const long wg64 = (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64);
         if (!no_sk && (cfg == 6 || cfg == 8) && wg64 <= 192 && (L.Kpad / EV_BK) * L.ntaps >= 8) cfg = 9;
+        // ... and when even those are only a few dozen workgroups: 32 x 32 tiles, four times as many CUs (EV_SK32_MAX, A/B)
+        static const int sk32_max = getenv("EV_SK32_MAX") ? atoi(getenv("EV_SK32_MAX")) : 96;
+        if (cfg == 9 && wg64 <= sk32_max && L.Cout >= 32) cfg = 19;
     }
     {   // A/B override for the stacked sparse-tap layers only (a 3-tap conv over a 1x1 conv): EV_SPARSE_CFG=<cfg>[,<min rows>]
         static const char* senv = getenv("EV_SPARSE_CFG");
@@ -531,7 +536,10 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         launch_cfg<64, 64, 2, 2, true>(p, h->stream, lo);
     } else if (cfg == 9) {   // 64 x 64 tiles, 16 waves, split-K inside the workgroup
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_sk(p, h->stream, lo);
+        launch_sk<4>(p, h->stream, lo);
+    } else if (cfg == 19) {  // 32 x 32 tiles, 8 waves, split-K eight ways
+        p.mtiles = (L.Cout + 31) / 32; p.ntiles = (g.nrows + 31) / 32; p.taplist = L.taplist[2]; p.nact_tab = L.nact[2]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_sk<1>(p, h->stream, lo);
     } else if (cfg == 6) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 64, 2, 2>(p, h->stream, lo);

@@ -657,9 +657,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 // (group 0 + 1 + 2 + ...: deterministic) before group 0 runs the usual epilogue.  Same operands and products as
 // conv_gemm_kernel; only the summation order over k-chunks differs.
 // ---------------------------------------------------------------------------
-template <int KS, bool FULL_ACT, int LEAN>
-__global__ __launch_bounds__(256 * KS) void conv_gemm_sk_kernel(const ConvParams p) {
-    constexpr int BM = 64, BN = 64, NTHR = 256 * KS;
+// TW = 4: a 64 x 64 tile (2 x 2 waves of 32 x 32) x KS wave groups.  TW = 1: a 32 x 32 tile whose K loop is split over KS single
+// waves — the tile's MFMA work is bound to ONE CU's four matrix pipes however many waves share it (a 64 x 64 x 768 tile is 384
+// MFMAs = 10 us per SIMD), so a launch of a few dozen 64 x 64 tiles on 256 CUs is sped up by spreading it over four times as
+// many CUs, not by more waves per tile.
+template <int KS, bool FULL_ACT, int LEAN, int TW = 4>
+__global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvParams p) {
+    static_assert(TW == 4 || TW == 1, "tile waves");
+    constexpr int BM = TW == 4 ? 64 : 32, BN = BM, NTHR = 64 * TW * KS;
     constexpr int MAXKB = 8;                              // k-chunks staged per round
     constexpr int MAXPASS = (BN + EV_HALO) * MAXKB * 8 / NTHR;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -668,8 +673,8 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_sk_kernel(const ConvParams
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tw = wave & 3, ks = wave >> 2;
-    const int wm = tw >> 1, wn = tw & 1;
+    const int tw = wave % TW, ks = wave / TW;
+    const int wm = TW == 4 ? (tw >> 1) : 0, wn = TW == 4 ? (tw & 1) : 0;
     const int li = lane & 31, lh = lane >> 5;
     const int work = blockIdx.x;
     const int mt = work % p.mtiles, nt = work / p.mtiles;
@@ -784,17 +789,17 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_sk_kernel(const ConvParams
     }
     // ---- sum the KS partial tiles through LDS (aliases the X tile), fixed order
     ev_lds_barrier();
-    float* red = smem;                                    // [KS-1][4 tiles][16 regs][64 lanes]
+    float* red = smem;                                    // [KS-1][TW tiles][16 regs][64 lanes]
     if (ks > 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[(((ks - 1) * 4 + tw) * 16 + r) * 64 + lane] = acc[r];
+        for (int r = 0; r < 16; ++r) red[(((ks - 1) * TW + tw) * 16 + r) * 64 + lane] = acc[r];
     }
     ev_lds_barrier();
     if (ks > 0) return;                                   // s_barrier only counts surviving waves from here on
 #pragma unroll
     for (int k = 1; k < KS; ++k)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += red[(((k - 1) * 4 + tw) * 16 + r) * 64 + lane];
+        for (int r = 0; r < 16; ++r) acc[r] += red[(((k - 1) * TW + tw) * 16 + r) * 64 + lane];
     f32x16 accs[1][1];
     accs[0][0] = acc;
     if constexpr (LEAN != 0) conv_epilogue_lean<1, 1, LEAN>(p, accs, smem + tw * (32 * 36), m0 + wm * 32, n0 + wn * 32, lane);
