@@ -714,16 +714,20 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
     return 0;
 }
 
-int launch_attn(ev_handle* h, const float* QKV, int ld, float* O, int ldo, const float* rowmask, const Geom& g, int H) {
+// `part`: scratch for the split-key small-launch build, 4 * rows * (H*64 + 2*H) floats (null: always the one-launch kernel)
+int launch_attn(ev_handle* h, const float* QKV, int ld, float* O, int ldo, const float* rowmask, const Geom& g, int H, float* part = nullptr) {
     AttnParams p;
     p.QKV = QKV; p.ld = ld; p.O = O; p.ldo = ldo; p.rowmask = rowmask; p.S = g.S; p.P = g.P; p.T = g.T; p.H = H; p.scale = 0.125f;
     const int nwg = ((g.T + 127) / 128) * H * (g.nrows / g.S), nkt = (g.T + 31) / 32;
     static const bool no_sk = getenv("EV_NO_ATTN_SK") != nullptr;
-    if (!no_sk && nwg <= 64 && nkt >= 4) {   // far fewer workgroups than CUs: split the key tiles over two wave groups per workgroup
-        constexpr int KS = 2;
-        const size_t gs = (size_t)(2 * 32 * ATT_LDK + 32), mb = (size_t)(KS - 1) * 4 * 34 * 64;
-        const size_t smem = std::max((size_t)KS * gs, mb) * sizeof(float);
-        hipLaunchKernelGGL(attention_sk_kernel<KS>, dim3((g.T + 127) / 128, H, g.nrows / g.S), dim3(256 * KS), smem, h->stream, p);
+    if (!no_sk && part && nwg <= 64 && nkt >= 4) {   // far fewer workgroups than CUs: the key tiles of a query tile go to KS workgroups
+        AttnPartParams pp;
+        pp.a = p; pp.rows = g.nrows;
+        pp.KS = nkt >= 12 ? 4 : 2;
+        pp.PO = part; pp.PML = part + (size_t)4 * g.nrows * H * 64;
+        hipLaunchKernelGGL(attention_part_kernel, dim3((g.T + 127) / 128, H, (g.nrows / g.S) * pp.KS), dim3(256), 0, h->stream, pp);
+        const long tot = (long)g.nrows * H * 16;
+        hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, pp);
     } else {
         hipLaunchKernelGGL(attention_kernel, dim3((g.T + 127) / 128, H, g.nrows / g.S), dim3(256), 0, h->stream, p);
     }
@@ -749,6 +753,7 @@ struct EstBufs {
     float *rm0, *rm1, *X0, *state, *A0, *B0, *R0, *H0, *LN0, *QKV0, *ATT0, *FF0, *CAT1, *U1, *F0, *G0, *V0;
     float *A1, *B1, *R1, *H1, *LN1, *QKV1, *ATT1, *FF1, *CAT0, *D1, *D2, *M1, *UU;
     float *tv, *temb_in, *temb_a, *temb_b, *tproj;
+    float *ATTP;         // split-key attention partials: 4 x rows x (128 + 4) floats (level 0 size; the levels run one after the other)
     float *C1RMS;        // time-invariant (mu, spk) share of rn[0]'s [block1 conv | res_conv], 512 wide
     float *AR0, *AR1;    // [block1 conv | res_conv] outputs per level, 512 wide
 };
@@ -768,6 +773,7 @@ void plan_est(Bump& b, int B, int Tp, int in_ch, int nsteps, EstBufs& e) {
     e.D1 = b.take(n1 * 256); e.D2 = b.take(n1 * 256); e.M1 = b.take(n1 * 256); e.UU = b.take(n1 * 256);
     const size_t ns = nsteps;
     e.C1RMS = b.take(n0 * 512); e.AR0 = b.take(n0 * 512); e.AR1 = b.take(n1 * 512);
+    e.ATTP = b.take(n0 * 4 * (128 + 4));
     e.tv = b.take(ns); e.temb_in = b.take(ns * in_ch); e.temb_a = b.take(ns * 1024); e.temb_b = b.take(ns * 1024); e.tproj = b.take(ns * 1536);
 }
 
@@ -837,7 +843,7 @@ int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
 // ---------------------------------------------------------------------------
 // estimator forward (decoder.py:363-443).  On entry X0 holds [x*m | mu*m | spk*m].
 // ---------------------------------------------------------------------------
-struct LevelBufs { float *A, *Bf, *R, *H, *LN, *QKV, *ATT, *FF; const float* rm; Geom g; float* AR; };
+struct LevelBufs { float *A, *Bf, *R, *H, *LN, *QKV, *ATT, *FF; const float* rm; Geom g; float* AR; float* ATTP; };
 inline int g_rows32(const Geom& g) { return (g.nrows + 31) / 32; }
 
 int run_resnet(ev_handle* h, const ResnetW& w, const float* X, int ldx, const LevelBufs& L, const float* temb) {
@@ -870,7 +876,7 @@ int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z,
         if (launch_ln(h, L.H, 256, L.LN, 256, w.ln1g, w.ln1b, L.g)) return 1;
         if (launch_conv(h, w.qkv, L.LN, 256, L.QKV, 384, L.g, e)) return 1;
     }
-    if (launch_attn(h, L.QKV, 384, L.ATT, 128, L.rm, L.g, heads)) return 1;
+    if (launch_attn(h, L.QKV, 384, L.ATT, 128, L.rm, L.g, heads, L.ATTP)) return 1;
     Epi eo; eo.R = L.H; eo.ldr = 256;
     if (launch_conv(h, w.out, L.ATT, 128, L.H, 256, L.g, eo)) return 1;  // H <- attn + H (in place, element-wise aliasing only)
     if (fuse) return launch_mlp(h, 0, L.H, w.ln3g, w.ln3b, w.ff1, &w.ff2, w.alpha, w.binv, L.H, L.rm, Z, ldz, L.g);
@@ -885,8 +891,8 @@ int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z,
 int run_estimator(ev_handle* h, EstBufs& b, int step, float dt, bool euler) {
     const EstimatorW& w = h->est;
     const int heads = h->dims.heads;
-    LevelBufs L0{b.A0, b.B0, b.R0, b.H0, b.LN0, b.QKV0, b.ATT0, b.FF0, b.rm0, b.g0, b.AR0};
-    LevelBufs L1{b.A1, b.B1, b.R1, b.H1, b.LN1, b.QKV1, b.ATT1, b.FF1, b.rm1, b.g1, b.AR1};
+    LevelBufs L0{b.A0, b.B0, b.R0, b.H0, b.LN0, b.QKV0, b.ATT0, b.FF0, b.rm0, b.g0, b.AR0, b.ATTP};
+    LevelBufs L1{b.A1, b.B1, b.R1, b.H1, b.LN1, b.QKV1, b.ATT1, b.FF1, b.rm1, b.g1, b.AR1, b.ATTP};
     const float* tp = b.tproj + (size_t)step * 1536;
     // down 0 @T
     if (run_resnet0(h, w, b.X0, w.in_ch, L0, tp + 0 * 256, b.C1RMS)) return 1;

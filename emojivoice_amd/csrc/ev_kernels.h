@@ -1506,27 +1506,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
 }
 
 // ---------------------------------------------------------------------------
-// attention_sk_kernel: the small-launch build of attention_kernel.  A batch-1 decode has 6-10 workgroups per attention
-// launch, each a serial chain over all 9-17 key tiles (~2.8 us per tile: two barriers, 32 dependent MFMAs for the scores, the
-// softmax, 32 MFMAs for P.V): 27-48 us per launch, 60 launches per decode.  Here a workgroup is 4*KS waves: KS wave groups
-// share the 128 queries and split the key tiles (group g takes tiles g, g + KS, ...), each with its own K / V staging
-// buffers and its own online-softmax state; the KS partial states (m, l, O) are merged through LDS in a fixed order
-// (group 0 <- 1 <- 2 ...: deterministic) before group 0 normalises and stores.  Same products as attention_kernel; only the
-// order in which the key tiles' contributions are combined differs.
+// attention_part_kernel + attention_merge_kernel: the small-launch build of attention_kernel.  A batch-1 decode has 6-10
+// workgroups per attention launch, and each of their waves is a serial chain over all 9-17 key tiles: 64 MFMAs = 1.7 us of its
+// SIMD's matrix pipe per tile, i.e. the launch is bound by the pipes of the handful of CUs it runs on (27-48 us, 60 launches
+// per decode; splitting the key tiles over more waves of the SAME workgroup was measured to gain nothing).  Here the key
+// tiles are split over KS workgroups (blockIdx.z = utterance * KS + part; part p takes tiles p, p + KS, ...), each writing its
+// un-normalised online-softmax state (m, l, O) per query; a second small kernel merges the KS states in a fixed order
+// (deterministic) and normalises.  Same products as attention_kernel; only the order in which the key tiles' contributions
+// are combined differs.
 // ---------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(256 * KS) void attention_sk_kernel(const AttnParams p) {
-    constexpr int GS = 2 * 32 * ATT_LDK + 32;            // floats per group: K tile, V tile, mask row
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2, w = wave & 3, gt = tid & 255;
-    float* Ks = smem + grp * GS;
-    float* Vs = Ks + 32 * ATT_LDK;
-    float* Ms = Vs + 32 * ATT_LDK;
+struct AttnPartParams {
+    AttnParams a;
+    float* PO;      // [KS][rows][H*64] un-normalised partial outputs (row index as in O)
+    float* PML;     // [KS][rows][H][2] running max (log2 domain) and sum
+    int KS; int rows;
+};
+
+__global__ __launch_bounds__(256) void attention_part_kernel(const AttnPartParams pp) {
+    const AttnParams& p = pp.a;
+    __shared__ __attribute__((aligned(16))) float Ks[32 * ATT_LDK];
+    __shared__ __attribute__((aligned(16))) float Vs[32 * ATT_LDK];
+    __shared__ float Ms[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
-    const int b = blockIdx.z, hd = blockIdx.y;
-    const int q0 = blockIdx.x * 128 + w * 32;
+    const int b = blockIdx.z / pp.KS, part = blockIdx.z % pp.KS, hd = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
     const size_t rowbase = (size_t)b * p.S + p.P;
     const int HD = p.H * 64;
     const float* Qp = p.QKV + hd * 64;
@@ -1547,10 +1551,9 @@ __global__ __launch_bounds__(256 * KS) void attention_sk_kernel(const AttnParams
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float mrun = -1e30f, lrun = 0.f;
-    const bool wave_active = q0 < p.T;
+    const bool wave_active = __builtin_amdgcn_readfirstlane(q0) < p.T;
     const int nkt = (p.T + 31) / 32;
-    const int nit = (nkt + KS - 1) / KS;                  // every group runs the same number of (barrier) iterations
-    const int sr = gt >> 3, sc = (gt & 7) * 8;
+    const int sr = tid >> 3, sc = (tid & 7) * 8;
     f32x4 k0, k1, v0, v1;
     float mk;
     auto kv_load = [&](int kt) {
@@ -1563,20 +1566,18 @@ __global__ __launch_bounds__(256 * KS) void attention_sk_kernel(const AttnParams
             k0 = *(const f32x4*)kr; k1 = *(const f32x4*)(kr + 4);
             v0 = *(const f32x4*)vr; v1 = *(const f32x4*)(vr + 4);
         }
-        const int tm = kt * 32 + (gt & 31);
+        const int tm = kt * 32 + (tid & 31);
         mk = (tm < p.T) ? p.rowmask[rowbase + tm] : -1e30f;
     };
-    kv_load(grp);                                         // (a tile index beyond nkt loads zeros and a -1e30 mask: never used)
-    for (int it = 0; it < nit; ++it) {
-        const int kt = it * KS + grp;
-        const bool tile_ok = kt < nkt;                    // uniform per wave group
+    kv_load(part);
+    for (int kt = part; kt < nkt; kt += pp.KS) {
         __syncthreads();
         *(f32x4*)(Ks + sr * ATT_LDK + sc) = k0; *(f32x4*)(Ks + sr * ATT_LDK + sc + 4) = k1;
         *(f32x4*)(Vs + sr * ATT_LDK + sc) = v0; *(f32x4*)(Vs + sr * ATT_LDK + sc + 4) = v1;
-        if (gt < 32) Ms[gt] = mk * 1.44269504088896340736f;
+        if (tid < 32) Ms[tid] = mk * 1.44269504088896340736f;
         __syncthreads();
-        kv_load(kt + KS);
-        if (!wave_active || !tile_ok) continue;
+        if (kt + pp.KS < nkt) kv_load(kt + pp.KS);
+        if (!wave_active) continue;
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -1612,42 +1613,44 @@ __global__ __launch_bounds__(256 * KS) void attention_sk_kernel(const AttnParams
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], o1, 0, 0, 0);
         }
     }
-    // ---- merge the KS partial states through LDS (aliases the staging buffers), group 0 <- 1 <- 2 ...
-    __syncthreads();
-    float* mb = smem + ((grp > 0 ? grp - 1 : 0) * 4 + w) * (34 * 64);    // [34 values][64 lanes] per (group, query wave)
-    if (grp > 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { mb[r * 64 + lane] = o0[r]; mb[(16 + r) * 64 + lane] = o1[r]; }
-        mb[32 * 64 + lane] = mrun; mb[33 * 64 + lane] = lrun;
-    }
-    __syncthreads();
-    if (grp > 0) return;
-#pragma unroll
-    for (int g = 1; g < KS; ++g) {
-        const float* src = smem + ((g - 1) * 4 + w) * (34 * 64);
-        const float m1 = src[32 * 64 + lane], l1 = src[33 * 64 + lane];
-        const float mnew = fmaxf(mrun, m1);
-        const float a0 = __builtin_amdgcn_exp2f(mrun - mnew), a1 = __builtin_amdgcn_exp2f(m1 - mnew);
-        lrun = lrun * a0 + l1 * a1;
-        mrun = mnew;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0[r] = o0[r] * a0 + src[r * 64 + lane] * a1;
-            o1[r] = o1[r] * a0 + src[(16 + r) * 64 + lane] * a1;
-        }
-    }
     const int tq = q0 + li;
-    if (tq < p.T) {
-        const float inv = 1.0f / lrun;
-        float* orow = p.O + (rowbase + tq) * p.ldo + hd * 64;
+    if (tq < p.T) {   // un-normalised state of this part (a part without key tiles leaves m = -1e30, l = 0, O = 0)
+        const size_t row = (size_t)part * pp.rows + rowbase + tq;
+        float* orow = pp.PO + row * HD + hd * 64;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
-            f32x4 c = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+            f32x4 a = {o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
+            f32x4 c = {o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
             *(f32x4*)(orow + 8 * g + 4 * lh) = a;
             *(f32x4*)(orow + 32 + 8 * g + 4 * lh) = c;
         }
+        if (lh == 0) { float* ml = pp.PML + (row * p.H + hd) * 2; ml[0] = mrun; ml[1] = lrun; }
     }
+}
+
+// one thread per (frame, head, 4 dims): O = sum_p w_p O_p / sum_p w_p l_p,  w_p = 2^(m_p - max_p m_p), parts in ascending order
+__global__ __launch_bounds__(256) void attention_merge_kernel(const AttnPartParams pp) {
+    const AttnParams& p = pp.a;
+    const int HD = p.H * 64, per_row = HD / 4;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = idx / per_row;
+    const int c4 = (int)(idx % per_row) * 4, hd = c4 >> 6;
+    if (n >= pp.rows) return;
+    const int t = (int)(n % p.S) - p.P;
+    if (t < 0 || t >= p.T) return;
+    float mmax = -1e30f;
+    for (int k = 0; k < pp.KS; ++k) mmax = fmaxf(mmax, pp.PML[(((size_t)k * pp.rows + n) * p.H + hd) * 2]);
+    float l = 0.f;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < pp.KS; ++k) {
+        const float* ml = pp.PML + (((size_t)k * pp.rows + n) * p.H + hd) * 2;
+        const float w = __builtin_amdgcn_exp2f(ml[0] - mmax);
+        l += ml[1] * w;
+        const f32x4 v = *(const f32x4*)(pp.PO + ((size_t)k * pp.rows + n) * HD + c4);
+        o += v * w;
+    }
+    const float inv = 1.0f / l;
+    *(f32x4*)(p.O + (size_t)n * p.ldo + c4) = o * inv;
 }
 
 // ---------------------------------------------------------------------------
