@@ -1054,7 +1054,11 @@ int run_text_encoder(ev_handle* h, const int64_t* d_ids, const int32_t* d_len, c
             const long tot = (long)g.nrows * 2 * w.heads * (kc / 4);
             hipLaunchKernelGGL(enc_rope_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, QKV, 3 * C, (const float*)w.theta, w.heads, kc, kc / 2,
                                g.nrows, g.S, g.P, g.T);
-            hipLaunchKernelGGL(enc_attention_kernel, dim3((Tx + 3) / 4, w.heads, B), dim3(256), 0, st, (const float*)QKV, 3 * C, d_len, ATT, C, w.heads, kc, B, Tx, S, P,
+            const size_t att_smem = (size_t)(64 * (kc | 4) + 4 * kc + 4 * ((Tx + 63) & ~63)) * sizeof(float);
+            if (kc % 4 != 0 || kc > 128) return fail(h, "ev_text_encoder: channels per head must be a multiple of 4, at most 128");
+            if (att_smem > 160 * 1024) return fail(h, "ev_text_encoder: text too long for the attention workspace in LDS");
+            ensure_dyn_smem<enc_attention_kernel>(att_smem, h->device);
+            hipLaunchKernelGGL(enc_attention_kernel, dim3((Tx + 3) / 4, w.heads, B), dim3(256), att_smem, st, (const float*)QKV, 3 * C, d_len, ATT, C, w.heads, kc, B, Tx, S, P,
                                sqrtf((float)kc));
             HIPCHK(h, hipGetLastError());
         }

@@ -1003,6 +1003,11 @@ __global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kerne
 // ---------------------------------------------------------------------------
 // Wave / block reductions (64-wide wavefronts)
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -1799,41 +1804,81 @@ __global__ void enc_rope_kernel(float* QKV, int ld, const float* theta, int head
     x[j + half] = b * c + a * sn;
 }
 
-// MultiHeadAttention core of text_encoder.py:216-246 for one query frame per wavefront (kc <= 128 features per head:
-// two per lane): scores = q.k / sqrt(kc), keys beyond the utterance length are masked_fill(-1e4) in the reference, i.e.
-// they contribute exp(-1e4 - max) = 0 exactly to a valid query — they are skipped here; queries beyond the length give 0
-// (their output is masked by every consumer).  Online softmax over the keys.
+// MultiHeadAttention core of text_encoder.py:216-246, one query frame per wavefront, four per workgroup (kc <= 128 features per
+// head, kc % 4 == 0).  As the reference orders it: scores = q.k / sqrt(kc) for all keys, softmax, then p.v.  Keys beyond the
+// utterance length are masked_fill(-1e4) in the reference, i.e. they contribute exp(-1e4 - max) = 0 exactly to a valid query — they
+// are skipped here; queries beyond the length give 0 (their output is masked by every consumer).
+//   scores: the workgroup stages 64 keys x kc at a time in LDS and LANE j owns key j (a kc-long dot product per lane, q broadcast
+//   from LDS) — no cross-lane reduction per key, which made the one-key-at-a-time form of round 1 a 160 us launch at batch 1;
+//   p.v: lane d owns output features d and d + 64, the probabilities are broadcast from LDS, v rows are read coalesced from L2.
+// dynamic LDS: (64 * (kc | 4) + 4 * kc + 4 * ceil64(Tx)) floats.
 __global__ __launch_bounds__(256) void enc_attention_kernel(const float* QKV, int ld, const int32_t* lengths, float* O, int ldo,
                                                             int heads, int kc, int B, int Tx, int S, int P, float score_div) {
-    const int lane = threadIdx.x & 63;
-    const int tq = blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ __attribute__((aligned(16))) float enc_sm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int LDK = kc | 4, Txp = (Tx + 63) & ~63;           // key row stride: 4 (mod 8) floats, conflict-free for ds_read_b128
+    float* Ks = enc_sm;
+    float* Qs = Ks + 64 * LDK + wave * kc;
+    float* Pw = enc_sm + 64 * LDK + 4 * kc + wave * Txp;
     const int hh = blockIdx.y, b = blockIdx.z;
-    if (tq >= Tx) return;
+    const int tq = blockIdx.x * 4 + wave;
     const int len = lengths[b] < Tx ? lengths[b] : Tx;
     const size_t row0 = (size_t)b * S + P;
-    const bool act = 2 * lane < kc;
-    const int dq = hh * kc + (act ? 2 * lane : 0);
-    float2 o = make_float2(0.f, 0.f);
-    if (tq < len) {
-        float2 q = *(const float2*)(QKV + (row0 + tq) * ld + dq);
-        if (!act) q = make_float2(0.f, 0.f);
-        const float* Kb = QKV + row0 * ld + heads * kc + dq;
-        const float* Vb = QKV + row0 * ld + 2 * heads * kc + dq;
-        float m = -INFINITY, l = 0.f;
-        for (int j = 0; j < len; ++j) {
-            const float2 k = *(const float2*)(Kb + (size_t)j * ld);
-            const float2 v = *(const float2*)(Vb + (size_t)j * ld);
-            const float sc = wave_sum(q.x * k.x + q.y * k.y) / score_div;
-            const float mn = fmaxf(m, sc);
-            const float corr = expf(m - mn), pj = expf(sc - mn);
-            l = l * corr + pj;
-            o.x = o.x * corr + pj * v.x;
-            o.y = o.y * corr + pj * v.y;
-            m = mn;
+    const bool qok = tq < len;                               // (wave-uniform)
+    for (int d = lane; d < kc; d += 64) Qs[d] = qok ? QKV[(row0 + tq) * ld + hh * kc + d] : 0.f;
+    const float* Kb = QKV + row0 * ld + heads * kc + hh * kc;
+    const float* Vb = QKV + row0 * ld + 2 * heads * kc + hh * kc;
+    const int nkt = (len + 63) >> 6, f4 = kc >> 2;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                                     // the previous tile is consumed (first pass: publishes Qs)
+        for (int i = tid; i < 64 * f4; i += 256) {
+            const int r = i / f4, c = (i % f4) * 4, j = kt * 64 + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j < len) v = *(const f32x4*)(Kb + (size_t)j * ld + c);
+            *(f32x4*)(Ks + r * LDK + c) = v;
         }
-        o.x /= l; o.y /= l;
+        __syncthreads();
+        if (qok) {
+            const float* kr = Ks + lane * LDK;
+            float s = 0.f;
+            for (int d = 0; d < kc; d += 4) {
+                const f32x4 k4 = *(const f32x4*)(kr + d), q4 = *(const f32x4*)(Qs + d);
+                s += q4[0] * k4[0]; s += q4[1] * k4[1]; s += q4[2] * k4[2]; s += q4[3] * k4[3];
+            }
+            const int j = kt * 64 + lane;
+            Pw[j] = j < len ? s / score_div : -INFINITY;
+        }
     }
-    if (act) *(float2*)(O + (row0 + tq) * ldo + dq) = o;
+    float l = 1.f;
+    if (qok) {                                               // softmax over the wave's own score row (lane j touches j, j + 64, ...)
+        float m = -INFINITY;
+        for (int j = lane; j < nkt * 64; j += 64) m = fmaxf(m, Pw[j]);
+        m = wave_max(m);
+        float ls = 0.f;
+        for (int j = lane; j < nkt * 64; j += 64) { const float e = expf(Pw[j] - m); Pw[j] = e; ls += e; }
+        l = wave_sum(ls);
+    }
+    __syncthreads();                                         // every lane's probabilities are visible to the whole wave
+    if (tq >= Tx) return;
+    float o0 = 0.f, o1 = 0.f;
+    if (qok) {
+        const bool a0 = lane < kc, a1 = lane + 64 < kc;
+        const float* v0 = Vb + (a0 ? lane : 0);
+        const float* v1 = Vb + (a1 ? lane + 64 : 0);
+        int j = 0;
+        for (; j + 4 <= len; j += 4) {
+            const f32x4 pj = *(const f32x4*)(Pw + j);
+            const float x0 = v0[(size_t)j * ld], x1 = v0[(size_t)(j + 1) * ld], x2 = v0[(size_t)(j + 2) * ld], x3 = v0[(size_t)(j + 3) * ld];
+            const float y0 = v1[(size_t)j * ld], y1 = v1[(size_t)(j + 1) * ld], y2 = v1[(size_t)(j + 2) * ld], y3 = v1[(size_t)(j + 3) * ld];
+            o0 += (pj[0] / l) * x0; o0 += (pj[1] / l) * x1; o0 += (pj[2] / l) * x2; o0 += (pj[3] / l) * x3;
+            o1 += (pj[0] / l) * y0; o1 += (pj[1] / l) * y1; o1 += (pj[2] / l) * y2; o1 += (pj[3] / l) * y3;
+        }
+        for (; j < len; ++j) { const float pj = Pw[j] / l; o0 += pj * v0[(size_t)j * ld]; o1 += pj * v1[(size_t)j * ld]; }
+    }
+    float* orow = O + (row0 + tq) * ldo + hh * kc;
+    if (lane < kc) orow[lane] = o0;
+    if (lane + 64 < kc) orow[lane + 64] = o1;
 }
 
 // Hard monotonic alignment + expansion (utils/model.py:29-41 generate_path, matcha_tts.py:131-135): one workgroup per
