@@ -401,12 +401,18 @@ void launch_cfg2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
 template <bool FULL, int LEAN, int TW>
 void launch_sk2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     constexpr int KS = TW == 4 ? 4 : 8, BN = TW == 4 ? 64 : 32;
-    const int nchunks = p.Kpad / EV_BK, kbs = nchunks < 8 ? nchunks : 8;
-    const size_t xs = 2 * EV_MAX_TAPS + (size_t)(BN + ((lo.halo + 7) & ~7)) * (32 * kbs + 4);
+    // k-chunks per staging round: TW = 4 up to 8; TW = 1 the whole K when the X tile fits LDS (<= 150 KB) and the per-thread
+    // staging registers (EV_SK_MAXF4), else the largest multiple of KS that does
+    const int nchunks = p.Kpad / EV_BK, rows = BN + ((lo.halo + 7) & ~7);
+    int kbs = nchunks < (TW == 4 ? 8 : 32) ? nchunks : (TW == 4 ? 8 : 32);
+    while (kbs > 8 && ((size_t)rows * (32 * kbs + 4) * 4 > 150 * 1024 || rows * kbs * 8 > EV_SK_MAXF4(TW))) kbs = (kbs - 1) & ~7;
+    const size_t xs = 2 * EV_MAX_TAPS + (size_t)rows * (32 * kbs + 4);
     const size_t red = (size_t)(KS - 1) * TW * 16 * 64, es = (size_t)TW * 32 * 36;
     size_t smem = std::max(xs, std::max(red, es)) * sizeof(float);
+    ConvParams q = p;
+    q.sk_kb = kbs;
     ensure_dyn_smem<conv_gemm_sk_kernel<KS, FULL, LEAN, TW>>(smem, lo.device);
-    hipLaunchKernelGGL((conv_gemm_sk_kernel<KS, FULL, LEAN, TW>), dim3(p.mtiles * p.ntiles), dim3(64 * TW * KS), smem, st, p);
+    hipLaunchKernelGGL((conv_gemm_sk_kernel<KS, FULL, LEAN, TW>), dim3(p.mtiles * p.ntiles), dim3(64 * TW * KS), smem, st, q);
 }
 template <int TW>
 void launch_sk(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
@@ -427,6 +433,12 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     p.Y = Y; p.ldy = ldy; p.Cout = L.Cout; p.osplit_log2 = e.osplit_log2; p.osstride = e.osstride; p.mmul = e.mmul;
     p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T;
     p.ntaps = L.ntaps; for (int i = 0; i < L.ntaps; ++i) p.off[i] = L.off[i];
+    if (!L.sparse_taps) {   // evenly spaced taps of a dense layer: the list is arithmetic, no fetch
+        bool even = true;
+        const int d = L.ntaps > 1 ? L.off[1] - L.off[0] : 0;
+        for (int i = 2; i < L.ntaps; ++i) even = even && (L.off[i] - L.off[i - 1] == d);
+        if (even) { p.ktaps_n = L.ntaps; p.plane_bytes = (L.Mpad / 32) * (L.Kpad / 8) * 1024; p.koff0 = L.off[0]; p.kdoff = d; }
+    }
     p.halo_lo = L.halo_lo; p.halo_hi = L.halo_hi;
     p.pro_lrelu = e.pro_slope >= 0.f; p.pro_slope = e.pro_slope;
     p.act = e.act; p.act_slope = e.act_slope; p.act_a = e.act_a; p.act_b = e.act_b;
@@ -539,7 +551,20 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         launch_sk<4>(p, h->stream, lo);
     } else if (cfg == 19) {  // 32 x 32 tiles, 8 waves, split-K eight ways
         p.mtiles = (L.Cout + 31) / 32; p.ntiles = (g.nrows + 31) / 32; p.taplist = L.taplist[2]; p.nact_tab = L.nact[2]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_sk<1>(p, h->stream, lo);
+        static const bool no_sk32_lean = getenv("EV_NO_SK32_LEAN") != nullptr;
+        static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
+        const int xr = 32 + p.halo_lo + p.halo_hi;
+        // conv_sk32_kernel's preconditions (everything else: the general small-launch build)
+        const bool fast = !no_sk32_lean && !no_lean && lean_ok(p) && p.ktaps_n > 0 && p.isplit_log2 >= 31 && !p.pro_lrelu && p.Cin == p.Kpad &&
+                          (p.Kpad == 256 || p.Kpad == 512 || p.Kpad == 1024) && (ldx % 4) == 0 && xr <= 16 * (512 / (p.Kpad / 4)) && (size_t)g.nrows * ldx * 4 < ((size_t)1 << 31) &&
+                          (size_t)xr * (p.Kpad + 4) * 4 <= 150 * 1024;
+        if (fast) {
+            const size_t smem = std::max((size_t)xr * (p.Kpad + 4), (size_t)7 * 16 * 64) * sizeof(float);
+            const dim3 grid(p.mtiles, p.ntiles);
+            if (p.act == ACT_SNAKE) { ensure_dyn_smem<conv_sk32_kernel<2>>(smem, h->device); hipLaunchKernelGGL(conv_sk32_kernel<2>, grid, dim3(512), smem, h->stream, p); }
+            else if (lean_acc(p)) { ensure_dyn_smem<conv_sk32_kernel<3>>(smem, h->device); hipLaunchKernelGGL(conv_sk32_kernel<3>, grid, dim3(512), smem, h->stream, p); }
+            else { ensure_dyn_smem<conv_sk32_kernel<1>>(smem, h->device); hipLaunchKernelGGL(conv_sk32_kernel<1>, grid, dim3(512), smem, h->stream, p); }
+        } else launch_sk<1>(p, h->stream, lo);
     } else if (cfg == 6) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 64, 2, 2>(p, h->stream, lo);
@@ -1703,7 +1728,8 @@ int ev_dbg_conv_bench(ev_handle* h, int Cin, int Cout, int K, int dil, int B, in
     const int stagger = (dbg & 64) ? 0 : -1;   // bit 64: disable the start stagger
     const bool planar = (dbg & 32) != 0;      // bit 32: channel-chunk-planar activations
     const bool no_res = (dbg & 128) != 0;     // bit 128: no residual input
-    dbg &= ~(64 | 32 | 128);
+    const bool no_pro = (dbg & 512) != 0;     // bit 512: no prologue activation (the estimator's layers)
+    dbg &= ~(64 | 32 | 128 | 512);
     if (!h) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     h->stream = nullptr;
@@ -1726,7 +1752,7 @@ int ev_dbg_conv_bench(ev_handle* h, int Cin, int Cout, int K, int dil, int B, in
     for (auto& v : xh) { s = s * 1664525u + 1013904223u; v = (s >> 8) * (1.0f / 16777216.0f) - 0.5f; }
     for (size_t o = 0; o < nx; o += xh.size()) HIPCHK(h, hipMemcpy(X + o, xh.data(), std::min(xh.size(), nx - o) * 4, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemset(Y, 0, ny * 4));
-    Epi e; e.pro_slope = 0.1f; e.dbg = dbg; e.force_cfg = cfg; e.stagger = stagger;
+    Epi e; e.pro_slope = no_pro ? -1.f : 0.1f; e.dbg = dbg; e.force_cfg = cfg; e.stagger = stagger;
     unsigned long long* d_st = nullptr;
     const size_t max_wgs = 1 << 16;
     if (dbg & 16) { HIPCHK(h, hipMalloc((void**)&d_st, max_wgs * 4 * 8)); HIPCHK(h, hipMemset(d_st, 0, max_wgs * 4 * 8)); e.stamps = d_st; }

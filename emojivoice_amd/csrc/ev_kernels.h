@@ -27,6 +27,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define EV_BK 32          // k (input-channel) chunk per LDS stage
 #define EV_LDK 36         // LDS row stride in floats (32 + 4 pad)
 #define EV_WROWS 128      // weight rows per LDS stage (= taps_per_stage * BM)
+// conv_gemm_sk_kernel: float4 of the X tile one staging round may hold (TW = 4: (64 + 64) rows x 8 chunks; TW = 1: 16 per thread = 32 rows x all 1024 input channels of the widest 1x1 layer)
+#define EV_SK_MAXF4(TW) ((TW) == 4 ? (64 + 64) * 8 * 8 : 16 * 512)
 #define EV_HALO 64        // max halo rows (lo + hi) an X tile may carry
 
 enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SILU = 3, ACT_MISH = 4, ACT_SNAKE = 5 };
@@ -53,6 +55,9 @@ struct ConvParams {
     int act2_lrelu; float act2_slope; int mask2;
     const float* rowmask;
     float* Y2; int ldy2;                    // optional second output = v * rowmask
+    int ktaps_n, plane_bytes, koff0, kdoff; // dense layers (every tap in every tile) with evenly spaced taps: tap i = {i * plane_bytes,
+                                            // koff0 + i * kdoff} — conv_gemm_sk_kernel derives the list from the kernel arguments instead of fetching it
+    int sk_kb;                              // conv_gemm_sk_kernel: k-chunks per staging round
     int stagger_slots;                      // workgroups co-resident per CU (0 = no start stagger), see conv_gemm_kernel
     unsigned long long* stamps;             // dbg bit 16: per-workgroup {start, first stage done, K loop done, end} s_memtime stamps
     int dbg;                                // ablation bits for tools/conv_bench.py: 1 skip X loads, 2 skip A loads, 4 skip epilogue
@@ -284,9 +289,12 @@ __device__ __forceinline__ float ev_div3(float x) {   // correctly rounded x / 3
     const float q = x * 0.333333343267440796f;
     return fmaf(fmaf(-3.f, q, x), 0.333333343267440796f, q);
 }
-template <int TM, int TN, int MODE = 1>
+struct EvNoHook { __device__ __forceinline__ void operator()() const {} };
+// `after_issue` runs between the request of the first slab's residual / mask rows and the barrier in front of the transposition
+// (conv_gemm_sk_kernel sums its partial tiles there, in the shadow of those loads; it may still modify acc).
+template <int TM, int TN, int MODE = 1, class Hook = EvNoHook>
 __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane,
-                                                   int win_lo = -0x7fffffff, int win_hi = 0x7fffffff) {
+                                                   int win_lo = -0x7fffffff, int win_hi = 0x7fffffff, Hook after_issue = Hook()) {
     constexpr int EC = TM * 32, ELD = EC + 4, C4 = EC / 4, RPP = 64 / C4, NP = 32 / RPP;
     const int li = lane & 31, lh = lane >> 5;
     const int er = lane / C4, ec = (lane % C4) * 4;
@@ -337,6 +345,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     const int lim = p.S - p.P;                        // t walks in [-P, S - P); S >= 4 (host: lean_ok), so two conditional wraps cover RPP <= 8
 #pragma unroll
     for (int q = 0; q < NP; ++q) issue_one(q);
+    after_issue();
     ev_lds_barrier();                                 // every wave is done reading the X tile: LDS can be reused
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -661,15 +670,32 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 // waves — the tile's MFMA work is bound to ONE CU's four matrix pipes however many waves share it (a 64 x 64 x 768 tile is 384
 // MFMAs = 10 us per SIMD), so a launch of a few dozen 64 x 64 tiles on 256 CUs is sped up by spreading it over four times as
 // many CUs, not by more waves per tile.
+// Latency order of a workgroup (a launch is ~one workgroup per CU, so its duration IS this chain): dense layers carry
+// their tap list in the kernel arguments (tap i = {i * plane_bytes, koff0 + i * kdoff}), so each wave issues the weight fragments of its first NPRE (chunk,
+// tap) steps straight from the kernarg scalars — before, and in the shadow of, the X staging; TW = 1 stages up to 32 k-chunks at
+// once (the whole K of every U-Net layer: one staging episode, one barrier).  Round 1 fetched the tap list through LDS, started
+// the first weight load after the staging barrier and kept one step in flight: three to five exposed memory latencies per launch.
 template <int KS, bool FULL_ACT, int LEAN, int TW = 4>
-__global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvParams pk) {
     static_assert(TW == 4 || TW == 1, "tile waves");
     constexpr int BM = TW == 4 ? 64 : 32, BN = BM, NTHR = 64 * TW * KS;
-    constexpr int MAXKB = 8;                              // k-chunks staged per round
-    constexpr int MAXPASS = (BN + EV_HALO) * MAXKB * 8 / NTHR;
+    constexpr int MAXPASS = EV_SK_MAXF4(TW) / NTHR;       // float4 of the X tile a thread stages per round
+    constexpr int NPRE = TW == 1 ? 4 : 1;                 // (chunk, tap) steps whose weight fragments are issued up front
     extern __shared__ __attribute__((aligned(16))) float smem[];
     int2* taps = (int2*)smem;                             // the (<= 16) tap-list entries of this M tile, then the X tile
     float* Xs = smem + 2 * EV_MAX_TAPS;
+    // Every kernel argument this kernel touches, fetched as ONE batch of scalar loads into a local copy whose fields are opaque to
+    // the compiler from here on ("+s": they cannot be re-fetched).  hipcc otherwise loads each field right in front of its first
+    // use and, short of SGPRs, AGAIN in front of later uses: ~20 dependent s_load / s_waitcnt round trips of ~0.3 us each in a
+    // row — most of the 4.2 us between the start of a workgroup and its staging barrier (per-workgroup stamps,
+    // tools/conv_bench.py 16:-1 / 1040:-1 / 2064:-1; profiles/r02_sk32_workgroup_timeline.log).
+    ConvParams p = pk;
+    asm volatile("" : "+s"(p.X), "+s"(p.ldx), "+s"(p.Cin), "+s"(p.isplit_log2), "+s"(p.isstride), "+s"(p.W), "+s"(p.Kpad), "+s"(p.bias),
+                      "+s"(p.Y), "+s"(p.ldy), "+s"(p.Cout), "+s"(p.nrows), "+s"(p.S), "+s"(p.P), "+s"(p.T));
+    asm volatile("" : "+s"(p.ntaps), "+s"(p.halo_lo), "+s"(p.halo_hi), "+s"(p.taplist), "+s"(p.tl_stride), "+s"(p.nact_tab), "+s"(p.mtiles),
+                      "+s"(p.pro_slope), "+s"(p.pro_lrelu), "+s"(p.act), "+s"(p.act_slope), "+s"(p.act_a), "+s"(p.act_b), "+s"(p.mask1), "+s"(p.R));
+    asm volatile("" : "+s"(p.ldr), "+s"(p.accum), "+s"(p.div3), "+s"(p.act2_lrelu), "+s"(p.act2_slope), "+s"(p.mask2), "+s"(p.rowmask),
+                      "+s"(p.ktaps_n), "+s"(p.plane_bytes), "+s"(p.koff0), "+s"(p.kdoff), "+s"(p.sk_kb), "+s"(p.stamps), "+s"(p.dbg));
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -687,29 +713,20 @@ __global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvPa
         else dist = p.S - (n0 % p.S) + p.P;
         if (dist >= BN || n0 + dist >= p.nrows) return;
     }
+    if ((p.dbg & 16) && tid == 0) p.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+#ifdef EV_NOPSLED
+    asm volatile(".rept 1024\n s_nop 0\n .endr" ::: "memory");   // probe: 4 KB of straight-line code on the path
+#endif
+    const bool ktp = p.ktaps_n > 0;                       // tap list in the kernel arguments
     const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
-    const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
-    if (tid < nact) taps[tid] = tl[tid];                  // (published by the first staging barrier)
+    int nact = p.ntaps;
+    if (!ktp && p.nact_tab) nact = __builtin_amdgcn_readfirstlane(p.nact_tab[mt]);
+    if (!ktp && tid < nact) taps[tid] = tl[tid];          // (published by the first staging barrier)
     const int nchunks = p.Kpad / EV_BK;
-    const int KBs = nchunks < MAXKB ? nchunks : MAXKB;    // k-chunks per staging round
-    const int LDKs = 32 * KBs + 4;                        // row stride: 4 or 36 (mod 64) floats, conflict-free for ds_read_b128
+    const int KBs = p.sk_kb;                              // k-chunks per staging round (host: fits LDS and MAXPASS)
+    const int LDKs = 32 * KBs + 4;                        // row stride: 4 (mod 32) floats, conflict-free for ds_read_b128
     const int xrows = BN + p.halo_lo + p.halo_hi;
 
-    f32x16 acc;
-    {
-        f32x4 bq[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            bq[g] = z;
-            if constexpr (LEAN != 0) {
-                const int c0 = m0 + wm * 32 + 8 * g + 4 * lh;
-                if (ks == 0 && p.bias && c0 < p.Cout) bq[g] = *(const f32x4*)(p.bias + c0);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = bq[r >> 2][r & 3];
-    }
     const int mt32 = (m0 + wm * 32) >> 5;
     const int KG8 = p.Kpad >> 3;
     const __amdgpu_buffer_rsrc_t rW = ev_rsrc(p.W), rX = ev_rsrc(p.X);
@@ -718,92 +735,313 @@ __global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvPa
     const int f4row = KBs * 8;                            // float4 per staged row
     const int nf4 = xrows * f4row;
 
+    // ---- weight fragments of this wave's first steps of round 0 (step s: tap s % nact of chunk ks + (s / nact) * KS)
+    f32x4 A[NPRE][4];
+    int2 tvs[NPRE];
+    int cs[NPRE];
+    int ti0 = 0, cn0 = ks;
+    const int kb0 = nchunks < KBs ? nchunks : KBs;
+    const int npre = __builtin_amdgcn_readfirstlane(ktp && kb0 > ks ? (((kb0 - ks + KS - 1) / KS) * nact < NPRE ? ((kb0 - ks + KS - 1) / KS) * nact : NPRE) : 0);
+#pragma unroll
+    for (int s = 0; s < NPRE; ++s) {
+        tvs[s] = make_int2(0, 0); cs[s] = 0;
+        if (s < npre) {
+            const int2 tv = make_int2(ti0 * p.plane_bytes, p.koff0 + ti0 * p.kdoff);
+            tvs[s] = tv; cs[s] = cn0;
+            const unsigned ap = (unsigned)tv.x + wbase + (unsigned)(cn0 * 4) * 1024u;
+            A[s][0] = ev_bload4(rW, wlane, ap); A[s][1] = ev_bload4(rW, wlane, ap + 1024u);
+            A[s][2] = ev_bload4(rW, wlane, ap + 2048u); A[s][3] = ev_bload4(rW, wlane, ap + 3072u);
+            if (++ti0 == nact) { ti0 = 0; cn0 += KS; }
+        }
+    }
+
+    f32x16 acc;
+    f32x4 bq[4];                                          // (consumed after the staging barrier: no wait for it in front of the X loads)
+    {   // bias through a descriptor bounded by Cout (a null bias has zero records): out-of-range channels read 0, no branches
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (LEAN != 0 && ks == 0 && p.bias) ? p.Cout * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB, (unsigned)(m0 + wm * 32 + 8 * g + 4 * lh) * 4u, 0);
+    }
+    auto mfma16 = [&](const f32x4 (&a)[4], int2 tv, int c) {
+        const float* brow = Xs + (wn * 32 + li + p.halo_lo + tv.y) * LDKs + 4 * lh + c * 32;
+        const f32x4 b0 = *(const f32x4*)(brow), b1 = *(const f32x4*)(brow + 8);
+        const f32x4 b2 = *(const f32x4*)(brow + 16), b3 = *(const f32x4*)(brow + 24);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s4], b0[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][s4], b1[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][s4], b2[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3][s4], b3[s4], acc, 0, 0, 0);
+    };
+
     for (int c0 = 0; c0 < nchunks; c0 += KBs) {
         const int kb = (nchunks - c0 < KBs) ? nchunks - c0 : KBs;
         ev_lds_barrier();                                 // the previous round's MFMAs are done with Xs
-        {   // ---- all threads stage kb chunks of the X tile: loads first, then (prologue +) LDS writes
+        if ((p.dbg & 16) && tid == 0 && c0 == 0 && ((p.dbg >> 10) & 3) == 2) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        {   // ---- all threads stage kb chunks of the X tile: loads first, then (prologue +) LDS writes.  Element i = q * NTHR + tid is
+            // (row i / f4row, float4 column i % f4row): one division per thread, then a carry walk per pass — two waves share a SIMD
+            // here, and a division per pass and per phase made this staging a 4 us VALU episode of an 11 us launch
             f32x4 xv[MAXPASS];
+            const int adv_r = NTHR / f4row, adv_c = NTHR % f4row;
+            const int r0 = tid / f4row, cc0 = tid - r0 * f4row;
+            int r = r0, cc = cc0;
 #pragma unroll
             for (int q = 0; q < MAXPASS; ++q) {
-                const int i = q * NTHR + tid;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (i < nf4) {
-                    const int r = i / f4row, c = (c0 * 8 + (i % f4row)) * 4;
+                if (q * NTHR < nf4) {
+                    const int c = (c0 * 8 + cc) * 4;
                     const int gr = n0 - p.halo_lo + r;
-                    if (c < p.Cin && (i % f4row) < kb * 8 && gr >= 0 && gr < p.nrows) {
+                    if (r < xrows && c < p.Cin && cc < kb * 8 && gr >= 0 && gr < p.nrows) {
                         const unsigned xcol = (unsigned)(c >> p.isplit_log2) * p.isstride + (c & ((1 << p.isplit_log2) - 1));
                         v = ev_bload4(rX, ((unsigned)gr * p.ldx + xcol) * 4u, 0);
                     }
                 }
                 xv[q] = v;
+                cc += adv_c; r += adv_r;
+                if (cc >= f4row) { cc -= f4row; ++r; }
             }
+            if ((p.dbg & 16) && tid == 0 && c0 == 0) {
+                const int set = (p.dbg >> 10) & 3;
+                if (set == 1) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+            }
+            r = r0; cc = cc0;
 #pragma unroll
             for (int q = 0; q < MAXPASS; ++q) {
-                const int i = q * NTHR + tid;
-                if (i < nf4) {
+                if (q * NTHR < nf4 && r < xrows) {
                     f32x4 v = xv[q];
                     if (p.pro_lrelu) {
                         v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
                         v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
                     }
-                    *(f32x4*)(Xs + (i / f4row) * LDKs + (i % f4row) * 4) = v;
+                    *(f32x4*)(Xs + r * LDKs + cc * 4) = v;
                 }
+                cc += adv_c; r += adv_r;
+                if (cc >= f4row) { cc -= f4row; ++r; }
             }
         }
+        if ((p.dbg & 16) && tid == 0 && c0 == 0 && ((p.dbg >> 10) & 3) == 3) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         ev_lds_barrier();
-        // ---- this wave group's chunks of the round (c = ks, ks + KS, ...) x taps, weight fragments one step ahead
-        const int nmy = (kb > ks) ? ((kb - ks + KS - 1) / KS) * nact : 0;
-        f32x4 an0, an1, an2, an3;
-        int2 tvn = make_int2(0, 0);
-        int cn = ks;
-        if (nmy > 0) {
-            tvn = ev_uniform(taps[0]);
-            const unsigned ap = (unsigned)tvn.x + wbase + (unsigned)((c0 + cn) * 4) * 1024u;
-            an0 = ev_bload4(rW, wlane, ap); an1 = ev_bload4(rW, wlane, ap + 1024u);
-            an2 = ev_bload4(rW, wlane, ap + 2048u); an3 = ev_bload4(rW, wlane, ap + 3072u);
+        if ((p.dbg & 16) && tid == 0 && c0 == 0 && ((p.dbg >> 10) & 3) == 0) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        if (c0 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = bq[r >> 2][r & 3];
         }
-        int ti = 0;
-        for (int it = 0; it < nmy; ++it) {
+        // ---- this wave group's chunks of the round (c = ks, ks + KS, ...) x taps
+        const int nmy = (kb > ks) ? ((kb - ks + KS - 1) / KS) * nact : 0;
+        int it0 = 0, ti = 0, cn = ks;
+        if (c0 == 0 && npre > 0) {                        // the steps whose fragments are already in registers
+#pragma unroll
+            for (int s = 0; s < NPRE; ++s)
+                if (s < npre) mfma16(A[s], tvs[s], cs[s]);
+            it0 = npre; ti = ti0; cn = cn0;
+        }
+        // (sparse tap lists, rounds after the first, steps beyond NPRE) weight fragments one step ahead
+        auto tap_at = [&](int i) -> int2 { return ktp ? make_int2(i * p.plane_bytes, p.koff0 + i * p.kdoff) : ev_uniform(taps[i]); };
+        f32x4 an[4];
+        int2 tvn = make_int2(0, 0);
+        if (it0 < nmy) {
+            tvn = tap_at(ti);
+            const unsigned ap = (unsigned)tvn.x + wbase + (unsigned)((c0 + cn) * 4) * 1024u;
+            an[0] = ev_bload4(rW, wlane, ap); an[1] = ev_bload4(rW, wlane, ap + 1024u);
+            an[2] = ev_bload4(rW, wlane, ap + 2048u); an[3] = ev_bload4(rW, wlane, ap + 3072u);
+        }
+        for (int it = it0; it < nmy; ++it) {
             const int2 tv = tvn;
             const int c = cn;
-            const f32x4 a0 = an0, a1 = an1, a2 = an2, a3 = an3;
+            const f32x4 a[4] = {an[0], an[1], an[2], an[3]};
             if (++ti == nact) { ti = 0; cn += KS; }
             if (it + 1 < nmy) {
-                tvn = ev_uniform(taps[ti]);
+                tvn = tap_at(ti);
                 const unsigned ap = (unsigned)tvn.x + wbase + (unsigned)((c0 + cn) * 4) * 1024u;
-                an0 = ev_bload4(rW, wlane, ap); an1 = ev_bload4(rW, wlane, ap + 1024u);
-                an2 = ev_bload4(rW, wlane, ap + 2048u); an3 = ev_bload4(rW, wlane, ap + 3072u);
+                an[0] = ev_bload4(rW, wlane, ap); an[1] = ev_bload4(rW, wlane, ap + 1024u);
+                an[2] = ev_bload4(rW, wlane, ap + 2048u); an[3] = ev_bload4(rW, wlane, ap + 3072u);
             }
-            const float* brow = Xs + (wn * 32 + li + p.halo_lo + tv.y) * LDKs + 4 * lh + c * 32;
-            const f32x4 b0 = *(const f32x4*)(brow), b1 = *(const f32x4*)(brow + 8);
-            const f32x4 b2 = *(const f32x4*)(brow + 16), b3 = *(const f32x4*)(brow + 24);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], b0[s4], acc, 0, 0, 0);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], b1[s4], acc, 0, 0, 0);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[s4], b2[s4], acc, 0, 0, 0);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a3[s4], b3[s4], acc, 0, 0, 0);
+            mfma16(a, tv, c);
         }
     }
     // ---- sum the KS partial tiles through LDS (aliases the X tile), fixed order
-    ev_lds_barrier();
+    if ((p.dbg & 16) && tid == 0) { if (acc[0] == 12345.678f) p.Y[0] = 1.f; p.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime(); }
     float* red = smem;                                    // [KS-1][TW tiles][16 regs][64 lanes]
     if (ks > 0) {
+        ev_lds_barrier();
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[(((ks - 1) * TW + tw) * 16 + r) * 64 + lane] = acc[r];
+        ev_lds_barrier();
+        return;                                           // s_barrier only counts surviving waves from here on
     }
-    ev_lds_barrier();
-    if (ks > 0) return;                                   // s_barrier only counts surviving waves from here on
-#pragma unroll
-    for (int k = 1; k < KS; ++k)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] += red[(((k - 1) * TW + tw) * 16 + r) * 64 + lane];
     f32x16 accs[1][1];
     accs[0][0] = acc;
-    if constexpr (LEAN != 0) conv_epilogue_lean<1, 1, LEAN>(p, accs, smem + tw * (32 * 36), m0 + wm * 32, n0 + wn * 32, lane);
-    else conv_epilogue<1, 1, FULL_ACT>(p, accs, smem + tw * (32 * 36), m0 + wm * 32, n0 + wn * 32, lane);
+    auto reduce = [&]() {                                 // (the same two barriers as the ks > 0 waves)
+        ev_lds_barrier();
+        ev_lds_barrier();
+#pragma unroll
+        for (int k = 1; k < KS; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[0][0][r] += red[(((k - 1) * TW + tw) * 16 + r) * 64 + lane];
+    };
+    if constexpr (LEAN != 0)   // the residual / mask rows of the epilogue are requested before the reduction, not after it
+        conv_epilogue_lean<1, 1, LEAN>(p, accs, smem + tw * (32 * 36), m0 + wm * 32, n0 + wn * 32, lane, -0x7fffffff, 0x7fffffff, reduce);
+    else {
+        reduce();
+        conv_epilogue<1, 1, FULL_ACT>(p, accs, smem + tw * (32 * 36), m0 + wm * 32, n0 + wn * 32, lane);
+    }
+    if ((p.dbg & 16) && tid == 0) p.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ---------------------------------------------------------------------------
+// conv_sk32_kernel: conv_gemm_sk_kernel<8, ., LEAN, 1> for the layers a batch-1 decode is made of, written for INSTRUCTION COUNT.
+// A launch of ~140 workgroups on 256 CUs is one serial chain per workgroup, and a wave issues at most one instruction every four
+// cycles (a 1024 x s_nop probe in the prologue of the general build cost 1.7 us: profiles/r02_sk32_workgroup_timeline.log), so
+// the ~1500 instruction-slots the general build spends between its first instruction and its staging barrier (index arithmetic
+// of a 16-pass unrolled staging with every layout option, tile-index divisions, 150 SGPR spills, kernel arguments fetched field
+// by field) ARE its 3.5 us prologue — more than its MFMAs.  Host-checked preconditions make that code disappear:
+//   dense layer with evenly spaced taps (tap list = arithmetic), Cin = Kpad in {256, 512, 1024} (one staging round, a thread's
+//   float4 column is fixed and its rows advance by a constant), plain row-major X without prologue activation, a lean epilogue,
+//   2-D grid (no tile-index division).
+// Same operands, products and summation order as conv_gemm_sk_kernel<8, false, LEAN, 1>.
+// ---------------------------------------------------------------------------
+template <int LEAN>
+__global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
+    constexpr int KS = 8, NTHR = 512, MAXPASS = 16, NPRE = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    ConvParams p = pk;          // one batch of scalar loads, opaque afterwards (see conv_gemm_sk_kernel)
+    asm volatile("" : "+s"(p.X), "+s"(p.ldx), "+s"(p.W), "+s"(p.Kpad), "+s"(p.bias), "+s"(p.Y), "+s"(p.ldy), "+s"(p.Cout), "+s"(p.nrows), "+s"(p.S),
+                      "+s"(p.P), "+s"(p.T), "+s"(p.ntaps), "+s"(p.halo_lo), "+s"(p.halo_hi));
+    asm volatile("" : "+s"(p.act), "+s"(p.act_slope), "+s"(p.act_a), "+s"(p.act_b), "+s"(p.mask1), "+s"(p.R), "+s"(p.ldr), "+s"(p.accum), "+s"(p.div3),
+                      "+s"(p.act2_lrelu), "+s"(p.act2_slope), "+s"(p.mask2), "+s"(p.rowmask), "+s"(p.plane_bytes), "+s"(p.koff0));
+    asm volatile("" : "+s"(p.kdoff), "+s"(p.stamps), "+s"(p.dbg));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    if ((p.dbg & 16) && tid == 0) p.stamps[4 * wg + 0] = __builtin_amdgcn_s_memrealtime();
+    const int LDK = p.Kpad + 4;
+    const int f4_log2 = 31 - __builtin_clz(p.Kpad) - 2;   // float4 per row = Kpad / 4 = 64, 128 or 256
+    const int adv_r = NTHR >> f4_log2;                    // rows a pass of all threads covers: 8, 4 or 2
+    const int xrows = 32 + p.halo_lo + p.halo_hi;
+    const int nact = p.ntaps;
+    const int nmy = (p.Kpad >> 8) * nact;                 // this wave's (chunk, tap) steps: chunks ks, ks + 8, ...
+    // (X through a descriptor bounded by the tensor — host: nrows * ldx * 4 < 2 GB — so that offset 0x80000000 reads zeros)
+    const __amdgpu_buffer_rsrc_t rW = ev_rsrc(p.W);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.nrows * p.ldx * 4, 0x00020000);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned wbase = (unsigned)(blockIdx.x * (p.Kpad >> 3)) * 1024u;
+
+    // ---- weight fragments of the first NPRE steps, bias: in flight across the whole staging
+    f32x4 A[NPRE][4];
+    int offs[NPRE], cs[NPRE];
+    int ti = 0, cn = ks;
+#pragma unroll
+    for (int s = 0; s < NPRE; ++s) {
+        offs[s] = 0; cs[s] = 0;
+        if (s < nmy) {
+            offs[s] = p.koff0 + ti * p.kdoff; cs[s] = cn;
+            const unsigned ap = (unsigned)(ti * p.plane_bytes) + wbase + (unsigned)(cn * 4) * 1024u;
+            A[s][0] = ev_bload4(rW, wlane, ap); A[s][1] = ev_bload4(rW, wlane, ap + 1024u);
+            A[s][2] = ev_bload4(rW, wlane, ap + 2048u); A[s][3] = ev_bload4(rW, wlane, ap + 3072u);
+            if (++ti == nact) { ti = 0; cn += KS; }
+        }
+    }
+    f32x4 bq[4];
+    {
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (ks == 0 && p.bias) ? p.Cout * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB, (unsigned)(m0 + 8 * g + 4 * lh) * 4u, 0);
+    }
+    // ---- X tile: thread = (row tid >> f4_log2 [+ adv_r per pass], float4 column tid & (f4 - 1)); rows outside the tensor read
+    // an out-of-range offset (the descriptor returns 0): no branches around the loads
+    {
+        f32x4 xv[MAXPASS];
+        const int r0 = tid >> f4_log2, c4 = tid & ((1 << f4_log2) - 1);
+        const int npass = (xrows - r0 + adv_r - 1) >> (9 - f4_log2);   // (per thread)
+        int gr = n0 - p.halo_lo + r0;
+        unsigned xo = ((unsigned)gr * (unsigned)p.ldx + (unsigned)c4 * 4u) * 4u;
+        const unsigned xstep = (unsigned)(adv_r * p.ldx) * 4u;
+#pragma unroll
+        for (int q = 0; q < MAXPASS; ++q) {
+            if (q * adv_r < xrows) {
+                xv[q] = ev_bload4(rX, (q < npass && (unsigned)gr < (unsigned)p.nrows) ? xo : 0x80000000u, 0);
+                gr += adv_r; xo += xstep;
+            }
+        }
+        float* dst = smem + r0 * LDK + c4 * 4;
+        const int dstep = adv_r * LDK;
+#pragma unroll
+        for (int q = 0; q < MAXPASS; ++q) {
+            if (q * adv_r < xrows) {
+                if (q < npass) *(f32x4*)dst = xv[q];
+                dst += dstep;
+            }
+        }
+    }
+    ev_lds_barrier();
+    if ((p.dbg & 16) && tid == 0) p.stamps[4 * wg + 1] = __builtin_amdgcn_s_memrealtime();
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bq[r >> 2][r & 3];
+    auto mfma16 = [&](const f32x4 (&a)[4], int off, int c) {
+        const float* brow = smem + (li + p.halo_lo + off) * LDK + 4 * lh + c * 32;
+        const f32x4 b0 = *(const f32x4*)(brow), b1 = *(const f32x4*)(brow + 8);
+        const f32x4 b2 = *(const f32x4*)(brow + 16), b3 = *(const f32x4*)(brow + 24);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0][s4], b0[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1][s4], b1[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2][s4], b2[s4], acc, 0, 0, 0);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3][s4], b3[s4], acc, 0, 0, 0);
+    };
+#pragma unroll
+    for (int s = 0; s < NPRE; ++s)
+        if (s < nmy) mfma16(A[s], offs[s], cs[s]);
+    if (nmy > NPRE) {                                     // (Cin = 512 with three taps: steps 4 and 5) one step ahead
+        f32x4 an[4];
+        int offn = p.koff0 + ti * p.kdoff;
+        {
+            const unsigned ap = (unsigned)(ti * p.plane_bytes) + wbase + (unsigned)(cn * 4) * 1024u;
+            an[0] = ev_bload4(rW, wlane, ap); an[1] = ev_bload4(rW, wlane, ap + 1024u);
+            an[2] = ev_bload4(rW, wlane, ap + 2048u); an[3] = ev_bload4(rW, wlane, ap + 3072u);
+        }
+#pragma unroll 1
+        for (int it = NPRE; it < nmy; ++it) {
+            const int off = offn, c = cn;
+            const f32x4 a[4] = {an[0], an[1], an[2], an[3]};
+            if (++ti == nact) { ti = 0; cn += KS; }
+            if (it + 1 < nmy) {
+                offn = p.koff0 + ti * p.kdoff;
+                const unsigned ap = (unsigned)(ti * p.plane_bytes) + wbase + (unsigned)(cn * 4) * 1024u;
+                an[0] = ev_bload4(rW, wlane, ap); an[1] = ev_bload4(rW, wlane, ap + 1024u);
+                an[2] = ev_bload4(rW, wlane, ap + 2048u); an[3] = ev_bload4(rW, wlane, ap + 3072u);
+            }
+            mfma16(a, off, c);
+        }
+    }
+    if ((p.dbg & 16) && tid == 0) { if (acc[0] == 12345.678f) p.Y[0] = 1.f; p.stamps[4 * wg + 2] = __builtin_amdgcn_s_memrealtime(); }
+    // ---- sum the eight partial tiles through LDS (aliases the X tile), fixed order 0 + 1 + ... + 7
+    float* red = smem;                                    // [7][16 regs][64 lanes]
+    if (ks > 0) {
+        ev_lds_barrier();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((ks - 1) * 16 + r) * 64 + lane] = acc[r];
+        ev_lds_barrier();
+        return;
+    }
+    f32x16 accs[1][1];
+    accs[0][0] = acc;
+    auto reduce = [&]() {
+        ev_lds_barrier();
+        ev_lds_barrier();
+#pragma unroll 1
+        for (int k = 0; k < KS - 1; ++k)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accs[0][0][r] += red[(k * 16 + r) * 64 + lane];
+    };
+    conv_epilogue_lean<1, 1, LEAN>(p, accs, smem, m0, n0, lane, -0x7fffffff, 0x7fffffff, reduce);
+    if ((p.dbg & 16) && tid == 0) p.stamps[4 * wg + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ---------------------------------------------------------------------------

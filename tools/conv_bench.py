@@ -20,7 +20,7 @@ shapes = [  # name, Cin, Cout, K, dil, T, P
     ("L3 k3", 64, 64, 3, 1, 66048, 512), ("L3 k11d5", 64, 64, 11, 5, 66048, 512),
     ("L4 k3", 32, 32, 3, 1, 132096, 1024), ("L4 k7d3", 32, 32, 7, 3, 132096, 1024), ("L4 k11d5", 32, 32, 11, 5, 132096, 1024),
     ("est k3 T", 256, 256, 3, 1, 516, 2), ("est 1x1 T", 256, 1024, 1, 1, 516, 2), ("est ff2 T", 1024, 256, 1, 1, 516, 2),
-    ("est k3 T/2", 256, 256, 3, 1, 258, 1),
+    ("est k3 T/2", 256, 256, 3, 1, 258, 1), ("est k3 512", 512, 256, 3, 1, 516, 2), ("est qkv", 256, 384, 1, 1, 516, 2),
 ]
 variants = [(0, -1), (1, -1), (2, -1), (4, -1), (7, -1)]
 if len(sys.argv) > 1:
@@ -30,7 +30,7 @@ only = os.environ.get("SHAPES")
 for name, cin, cout, k, d, T, P in shapes:
     if only and not any(name.startswith(o) for o in only.split(",")):
         continue
-    bb = B if not name.startswith("est") else 64
+    bb = B if not name.startswith("est") else int(os.environ.get("EST_B", "64"))
     flops = 2.0 * cin * cout * k * bb * T
     row = []
     for dbg, cfg in variants:
