@@ -740,16 +740,19 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
 }
 
 // `part`: scratch for the split-key small-launch build, 4 * rows * (H*64 + 2*H) floats (null: always the one-launch kernel)
+constexpr int EV_ATTN_MAXPARTS = 16;   // split-key attention (small launches): parts a query tile's key tiles may be spread over,
+constexpr int EV_ATTN_MAXROWS = 8192;  // and the most rows such a launch has (<= 64 workgroups of 128 queries, plus padding)
 int launch_attn(ev_handle* h, const float* QKV, int ld, float* O, int ldo, const float* rowmask, const Geom& g, int H, float* part = nullptr) {
     AttnParams p;
     p.QKV = QKV; p.ld = ld; p.O = O; p.ldo = ldo; p.rowmask = rowmask; p.S = g.S; p.P = g.P; p.T = g.T; p.H = H; p.scale = 0.125f;
     const int nwg = ((g.T + 127) / 128) * H * (g.nrows / g.S), nkt = (g.T + 31) / 32;
     static const bool no_sk = getenv("EV_NO_ATTN_SK") != nullptr;
-    if (!no_sk && part && nwg <= 64 && nkt >= 4) {   // far fewer workgroups than CUs: the key tiles of a query tile go to KS workgroups
+    if (!no_sk && part && nwg <= 64 && nkt >= 4 && g.nrows <= EV_ATTN_MAXROWS) {   // far fewer workgroups than CUs: the key tiles of a query tile go to KS workgroups
         AttnPartParams pp;
         pp.a = p; pp.rows = g.nrows;
-        pp.KS = nkt >= 12 ? 4 : 2;
-        pp.PO = part; pp.PML = part + (size_t)4 * g.nrows * H * 64;
+        static const int tpw = getenv("EV_ATTN_TPW") ? std::max(1, atoi(getenv("EV_ATTN_TPW"))) : 2;   // key tiles per workgroup (A/B)
+        pp.KS = std::min(EV_ATTN_MAXPARTS, (nkt + tpw - 1) / tpw);
+        pp.PO = part; pp.PML = part + (size_t)EV_ATTN_MAXPARTS * g.nrows * H * 64;
         hipLaunchKernelGGL(attention_part_kernel, dim3((g.T + 127) / 128, H, (g.nrows / g.S) * pp.KS), dim3(256), 0, h->stream, pp);
         const long tot = (long)g.nrows * H * 16;
         hipLaunchKernelGGL(attention_merge_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, pp);
@@ -778,7 +781,7 @@ struct EstBufs {
     float *rm0, *rm1, *X0, *state, *A0, *B0, *R0, *H0, *LN0, *QKV0, *ATT0, *FF0, *CAT1, *U1, *F0, *G0, *V0;
     float *A1, *B1, *R1, *H1, *LN1, *QKV1, *ATT1, *FF1, *CAT0, *D1, *D2, *M1, *UU;
     float *tv, *temb_in, *temb_a, *temb_b, *tproj;
-    float *ATTP;         // split-key attention partials: 4 x rows x (128 + 4) floats (level 0 size; the levels run one after the other)
+    float *ATTP;         // split-key attention partials: EV_ATTN_MAXPARTS x min(rows, EV_ATTN_MAXROWS) x (128 + 4) floats (the levels run one after the other)
     float *C1RMS;        // time-invariant (mu, spk) share of rn[0]'s [block1 conv | res_conv], 512 wide
     float *AR0, *AR1;    // [block1 conv | res_conv] outputs per level, 512 wide
 };
@@ -798,7 +801,7 @@ void plan_est(Bump& b, int B, int Tp, int in_ch, int nsteps, EstBufs& e) {
     e.D1 = b.take(n1 * 256); e.D2 = b.take(n1 * 256); e.M1 = b.take(n1 * 256); e.UU = b.take(n1 * 256);
     const size_t ns = nsteps;
     e.C1RMS = b.take(n0 * 512); e.AR0 = b.take(n0 * 512); e.AR1 = b.take(n1 * 512);
-    e.ATTP = b.take(n0 * 4 * (128 + 4));
+    e.ATTP = b.take(std::min<size_t>(n0, EV_ATTN_MAXROWS) * EV_ATTN_MAXPARTS * (128 + 4));
     e.tv = b.take(ns); e.temb_in = b.take(ns * in_ch); e.temb_a = b.take(ns * 1024); e.temb_b = b.take(ns * 1024); e.tproj = b.take(ns * 1536);
 }
 
