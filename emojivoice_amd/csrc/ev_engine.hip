@@ -36,6 +36,7 @@ struct ConvLayer {
     int2* taplist[3] = {nullptr, nullptr, nullptr};   // for BM = 128, 64, 32: [mtiles][EV_MAX_TAPS] {tap, row offset} (one shared row when dense)
     int* nact[3] = {nullptr, nullptr, nullptr};       // per-tile active tap count (null when dense)
     bool sparse_taps = false;
+    int kstack_mt = 0, kstack_tap = 0;      // sparse_taps of the stacked [k-tap conv | 1x1 conv] kind: 32-channel tiles >= kstack_mt carry only tap kstack_tap
     int ntaps = 0, off[EV_MAX_TAPS] = {0};
     int halo_lo = 0, halo_hi = 0;
     int Cin = 0, Cout = 0, Mpad = 0, Kpad = 0;
@@ -206,6 +207,14 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                 if (nz) lists[k][t].push_back(make_int2(tap * plane_bytes, L.off[tap]));
                 else if (t * BM < L.Cout) L.sparse_taps = true;
             }
+    }
+    if (L.sparse_taps) {   // the stacked pattern on the 32-channel tiling: full tiles first, then tiles with one and the same tap
+        const int mt = (L.Cout + 31) / 32;
+        int split = 0;
+        while (split < mt && (int)lists[2][split].size() == L.ntaps) ++split;
+        bool ok = split > 0 && split < mt;
+        for (int t = split; t < mt && ok; ++t) ok = lists[2][t].size() == 1 && lists[2][t][0].x == lists[2][split][0].x;
+        if (ok) { L.kstack_mt = split; L.kstack_tap = lists[2][split][0].x / plane_bytes; }
     }
     for (int k = 0; k < 3; ++k) {
         const int mt = L.Mpad / bms[k];
@@ -433,11 +442,15 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     p.Y = Y; p.ldy = ldy; p.Cout = L.Cout; p.osplit_log2 = e.osplit_log2; p.osstride = e.osstride; p.mmul = e.mmul;
     p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T;
     p.ntaps = L.ntaps; for (int i = 0; i < L.ntaps; ++i) p.off[i] = L.off[i];
-    if (!L.sparse_taps) {   // evenly spaced taps of a dense layer: the list is arithmetic, no fetch
+    if (!L.sparse_taps || L.kstack_mt > 0) {   // evenly spaced taps of a dense (or stacked) layer: the list is arithmetic, no fetch
         bool even = true;
         const int d = L.ntaps > 1 ? L.off[1] - L.off[0] : 0;
         for (int i = 2; i < L.ntaps; ++i) even = even && (L.off[i] - L.off[i - 1] == d);
-        if (even) { p.ktaps_n = L.ntaps; p.plane_bytes = (L.Mpad / 32) * (L.Kpad / 8) * 1024; p.koff0 = L.off[0]; p.kdoff = d; }
+        if (even) {
+            p.plane_bytes = (L.Mpad / 32) * (L.Kpad / 8) * 1024; p.koff0 = L.off[0]; p.kdoff = d;
+            if (!L.sparse_taps) p.ktaps_n = L.ntaps;
+            else { p.kstack_mt = L.kstack_mt; p.kstack_tap = L.kstack_tap; }
+        }
     }
     p.halo_lo = L.halo_lo; p.halo_hi = L.halo_hi;
     p.pro_lrelu = e.pro_slope >= 0.f; p.pro_slope = e.pro_slope;
@@ -491,6 +504,8 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         static const bool no_sk = getenv("EV_NO_SK") != nullptr;
         const long wg64 = (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64);
         if (!no_sk && (cfg == 6 || cfg == 8) && wg64 <= 192 && (L.Kpad / EV_BK) * L.ntaps >= 8) cfg = 9;
+        // (a short K loop gains nothing from the split, but the 32 x 32 build for it is the instruction-lean conv_sk32_kernel)
+        if (!no_sk && (cfg == 6 || cfg == 8) && wg64 <= 96 && L.Kpad == 128 && L.Cin == 128 && !L.sparse_taps) cfg = 9;
         // ... and when even those are only a few dozen workgroups: 32 x 32 tiles, four times as many CUs (EV_SK32_MAX, A/B)
         static const int sk32_max = getenv("EV_SK32_MAX") ? atoi(getenv("EV_SK32_MAX")) : 96;
         if (cfg == 9 && wg64 <= sk32_max && L.Cout >= 32) cfg = 19;
@@ -555,8 +570,8 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
         const int xr = 32 + p.halo_lo + p.halo_hi;
         // conv_sk32_kernel's preconditions (everything else: the general small-launch build)
-        const bool fast = !no_sk32_lean && !no_lean && lean_ok(p) && p.ktaps_n > 0 && p.isplit_log2 >= 31 && !p.pro_lrelu && p.Cin == p.Kpad &&
-                          (p.Kpad == 256 || p.Kpad == 512 || p.Kpad == 1024) && (ldx % 4) == 0 && xr <= 16 * (512 / (p.Kpad / 4)) && (size_t)g.nrows * ldx * 4 < ((size_t)1 << 31) &&
+        const bool fast = !no_sk32_lean && !no_lean && lean_ok(p) && (p.ktaps_n > 0 || p.kstack_mt > 0) && p.isplit_log2 >= 31 && !p.pro_lrelu && p.Cin == p.Kpad &&
+                          (p.Kpad == 128 || p.Kpad == 256 || p.Kpad == 512 || p.Kpad == 1024) && (ldx % 4) == 0 && xr <= 16 * (512 / (p.Kpad / 4)) && (size_t)g.nrows * ldx * 4 < ((size_t)1 << 31) &&
                           (size_t)xr * (p.Kpad + 4) * 4 <= 150 * 1024;
         if (fast) {
             const size_t smem = std::max((size_t)xr * (p.Kpad + 4), (size_t)7 * 16 * 64) * sizeof(float);

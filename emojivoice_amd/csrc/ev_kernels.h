@@ -57,6 +57,8 @@ struct ConvParams {
     float* Y2; int ldy2;                    // optional second output = v * rowmask
     int ktaps_n, plane_bytes, koff0, kdoff; // dense layers (every tap in every tile) with evenly spaced taps: tap i = {i * plane_bytes,
                                             // koff0 + i * kdoff} — conv_gemm_sk_kernel derives the list from the kernel arguments instead of fetching it
+    int kstack_mt, kstack_tap;              // stacked layers (a k-tap conv over a 1x1 conv along Cout): 32-channel tiles >= kstack_mt carry the
+                                            // single tap kstack_tap, the tiles below it all ntaps (0 = not such a layer); conv_sk32_kernel only
     int sk_kb;                              // conv_gemm_sk_kernel: k-chunks per staging round
     int stagger_slots;                      // workgroups co-resident per CU (0 = no start stagger), see conv_gemm_kernel
     unsigned long long* stamps;             // dbg bit 16: per-workgroup {start, first stage done, K loop done, end} s_memtime stamps
@@ -897,7 +899,7 @@ __global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvPa
 // the ~1500 instruction-slots the general build spends between its first instruction and its staging barrier (index arithmetic
 // of a 16-pass unrolled staging with every layout option, tile-index divisions, 150 SGPR spills, kernel arguments fetched field
 // by field) ARE its 3.5 us prologue — more than its MFMAs.  Host-checked preconditions make that code disappear:
-//   dense layer with evenly spaced taps (tap list = arithmetic), Cin = Kpad in {256, 512, 1024} (one staging round, a thread's
+//   dense layer with evenly spaced taps (tap list = arithmetic; or the stacked [k-tap conv | 1x1 conv] pattern: kstack_mt), Cin = Kpad in {128, 256, 512, 1024} (one staging round, a thread's
 //   float4 column is fixed and its rows advance by a constant), plain row-major X without prologue activation, a lean epilogue,
 //   2-D grid (no tile-index division).
 // Same operands, products and summation order as conv_gemm_sk_kernel<8, false, LEAN, 1>.
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
                       "+s"(p.P), "+s"(p.T), "+s"(p.ntaps), "+s"(p.halo_lo), "+s"(p.halo_hi));
     asm volatile("" : "+s"(p.act), "+s"(p.act_slope), "+s"(p.act_a), "+s"(p.act_b), "+s"(p.mask1), "+s"(p.R), "+s"(p.ldr), "+s"(p.accum), "+s"(p.div3),
                       "+s"(p.act2_lrelu), "+s"(p.act2_slope), "+s"(p.mask2), "+s"(p.rowmask), "+s"(p.plane_bytes), "+s"(p.koff0));
-    asm volatile("" : "+s"(p.kdoff), "+s"(p.stamps), "+s"(p.dbg));
+    asm volatile("" : "+s"(p.kdoff), "+s"(p.stamps), "+s"(p.dbg), "+s"(p.kstack_mt), "+s"(p.kstack_tap));
     const int tid = threadIdx.x, lane = tid & 63;
     const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -919,11 +921,12 @@ __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     if ((p.dbg & 16) && tid == 0) p.stamps[4 * wg + 0] = __builtin_amdgcn_s_memrealtime();
     const int LDK = p.Kpad + 4;
-    const int f4_log2 = 31 - __builtin_clz(p.Kpad) - 2;   // float4 per row = Kpad / 4 = 64, 128 or 256
-    const int adv_r = NTHR >> f4_log2;                    // rows a pass of all threads covers: 8, 4 or 2
+    const int f4_log2 = 31 - __builtin_clz(p.Kpad) - 2;   // float4 per row = Kpad / 4 = 32, 64, 128 or 256
+    const int adv_r = NTHR >> f4_log2;                    // rows a pass of all threads covers: 16, 8, 4 or 2
     const int xrows = 32 + p.halo_lo + p.halo_hi;
-    const int nact = p.ntaps;
-    const int nmy = (p.Kpad >> 8) * nact;                 // this wave's (chunk, tap) steps: chunks ks, ks + 8, ...
+    int nact = p.ntaps, t0 = 0;                           // this M tile's taps: t0, t0 + 1, ..., t0 + nact - 1
+    if (p.kstack_mt > 0 && (int)blockIdx.x >= p.kstack_mt) { nact = 1; t0 = p.kstack_tap; }
+    const int nmy = (((p.Kpad >> 5) + 7 - ks) >> 3) * nact;   // this wave's (chunk, tap) steps: chunks ks, ks + 8, ... < Kpad / 32
     // (X through a descriptor bounded by the tensor — host: nrows * ldx * 4 < 2 GB — so that offset 0x80000000 reads zeros)
     const __amdgpu_buffer_rsrc_t rW = ev_rsrc(p.W);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, p.nrows * p.ldx * 4, 0x00020000);
@@ -938,8 +941,8 @@ __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
     for (int s = 0; s < NPRE; ++s) {
         offs[s] = 0; cs[s] = 0;
         if (s < nmy) {
-            offs[s] = p.koff0 + ti * p.kdoff; cs[s] = cn;
-            const unsigned ap = (unsigned)(ti * p.plane_bytes) + wbase + (unsigned)(cn * 4) * 1024u;
+            offs[s] = p.koff0 + (t0 + ti) * p.kdoff; cs[s] = cn;
+            const unsigned ap = (unsigned)((t0 + ti) * p.plane_bytes) + wbase + (unsigned)(cn * 4) * 1024u;
             A[s][0] = ev_bload4(rW, wlane, ap); A[s][1] = ev_bload4(rW, wlane, ap + 1024u);
             A[s][2] = ev_bload4(rW, wlane, ap + 2048u); A[s][3] = ev_bload4(rW, wlane, ap + 3072u);
             if (++ti == nact) { ti = 0; cn += KS; }
@@ -1000,9 +1003,9 @@ __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
         if (s < nmy) mfma16(A[s], offs[s], cs[s]);
     if (nmy > NPRE) {                                     // (Cin = 512 with three taps: steps 4 and 5) one step ahead
         f32x4 an[4];
-        int offn = p.koff0 + ti * p.kdoff;
+        int offn = p.koff0 + (t0 + ti) * p.kdoff;
         {
-            const unsigned ap = (unsigned)(ti * p.plane_bytes) + wbase + (unsigned)(cn * 4) * 1024u;
+            const unsigned ap = (unsigned)((t0 + ti) * p.plane_bytes) + wbase + (unsigned)(cn * 4) * 1024u;
             an[0] = ev_bload4(rW, wlane, ap); an[1] = ev_bload4(rW, wlane, ap + 1024u);
             an[2] = ev_bload4(rW, wlane, ap + 2048u); an[3] = ev_bload4(rW, wlane, ap + 3072u);
         }
@@ -1012,8 +1015,8 @@ __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
             const f32x4 a[4] = {an[0], an[1], an[2], an[3]};
             if (++ti == nact) { ti = 0; cn += KS; }
             if (it + 1 < nmy) {
-                offn = p.koff0 + ti * p.kdoff;
-                const unsigned ap = (unsigned)(ti * p.plane_bytes) + wbase + (unsigned)(cn * 4) * 1024u;
+                offn = p.koff0 + (t0 + ti) * p.kdoff;
+                const unsigned ap = (unsigned)((t0 + ti) * p.plane_bytes) + wbase + (unsigned)(cn * 4) * 1024u;
                 an[0] = ev_bload4(rW, wlane, ap); an[1] = ev_bload4(rW, wlane, ap + 1024u);
                 an[2] = ev_bload4(rW, wlane, ap + 2048u); an[3] = ev_bload4(rW, wlane, ap + 3072u);
             }
