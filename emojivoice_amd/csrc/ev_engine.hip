@@ -50,6 +50,8 @@ struct Epi {
     float* Y2 = nullptr; int ldy2 = 0;
     float pro_slope = -1.f;                 // >= 0: prologue leaky-relu on the input
     int dbg = 0; int force_cfg = -1; int stagger = -1; unsigned long long* stamps = nullptr;
+    float* gn_part = nullptr;               // ask for the per-tile GroupNorm statistics of the output (conv_sk32_kernel, one utterance); whether
+                                            // they were produced is left in ev_handle::gn_stats_tiles (0 = no)
     int isplit_log2 = 31, isstride = 0;     // input column split (pair view of a strided slice)
     int osplit_log2 = 31, osstride = 0;     // output column split
 };
@@ -119,6 +121,7 @@ struct ev_handle {
     bool fuse_pairs = true;     // EV_FUSE_PAIRS=0 disables resblock_pair_kernel (A/B runs)
     int fuse128 = 3;            // fuse C=128 pairs up to this kernel size (EV_FUSE128=0/3/7/11)
     bool fuse_mlp = true;       // EV_FUSE_MLP=0: LayerNorm / QKV / feed-forward of the transformer blocks as separate launches
+    int gn_stats_tiles = 0;         // set by every launch_conv: row tiles whose GroupNorm statistics the launch left in Epi::gn_part (0 = none)
     int fuse_mlp_min_tiles = 96;    // EV_FUSE_MLP_MIN=<32-row tiles>: below this the separate (split-K) launches are used (measured with
                                     // tools/fuse_threshold.py at T = 516: batch 4 fused 13.4 / separate 12.1 ms, batch 8 15.1 / 15.2, batch 16 19.7 / 21.6)
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -434,9 +437,11 @@ void launch_sk(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     else launch_sk2<true, 0, TW>(p, st, lo);
 }
 
+constexpr int EV_GN_MAXTILES = 256;    // 32-row tiles of a launch that may leave GroupNorm statistics (EstBufs::GNP)
 int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {
     ConvParams p;
     memset(&p, 0, sizeof p);
+    h->gn_stats_tiles = 0;
     p.X = X; p.ldx = ldx; p.Cin = L.Cin; p.isplit_log2 = e.isplit_log2; p.isstride = e.isstride;
     p.W = L.W; p.Mpad = L.Mpad; p.Kpad = L.Kpad; p.bias = L.bias;
     p.Y = Y; p.ldy = ldy; p.Cout = L.Cout; p.osplit_log2 = e.osplit_log2; p.osstride = e.osstride; p.mmul = e.mmul;
@@ -576,6 +581,14 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         if (fast) {
             const size_t smem = std::max((size_t)xr * (p.Kpad + 4), (size_t)7 * 16 * 64) * sizeof(float);
             const dim3 grid(p.mtiles, p.ntiles);
+            // GroupNorm statistics of the output for the layer that follows: one utterance, the tile stored as accumulated, one
+            // 32-channel group per M tile over the (first) 256 output channels
+            static const bool no_gn_stats = getenv("EV_NO_GN_STATS") != nullptr;
+            if (!no_gn_stats && e.gn_part && g.nrows == g.S && p.ntiles <= EV_GN_MAXTILES && p.act == ACT_NONE && !p.R && !lean_acc(p) && !p.mask1 && !p.mask2 &&
+                (p.kstack_mt == 8 || (p.kstack_mt == 0 && L.Cout == 256))) {
+                p.gn_part = e.gn_part;
+                h->gn_stats_tiles = p.ntiles;
+            }
             if (p.act == ACT_SNAKE) { ensure_dyn_smem<conv_sk32_kernel<2>>(smem, h->device); hipLaunchKernelGGL(conv_sk32_kernel<2>, grid, dim3(512), smem, h->stream, p); }
             else if (lean_acc(p)) { ensure_dyn_smem<conv_sk32_kernel<3>>(smem, h->device); hipLaunchKernelGGL(conv_sk32_kernel<3>, grid, dim3(512), smem, h->stream, p); }
             else { ensure_dyn_smem<conv_sk32_kernel<1>>(smem, h->device); hipLaunchKernelGGL(conv_sk32_kernel<1>, grid, dim3(512), smem, h->stream, p); }
@@ -684,13 +697,16 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
 }
 
 int launch_gn(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const float* gamma, const float* beta, const float* rowmask,
-              const float* temb, const float* R, int ldr, const Geom& g, int C, int mode) {
+              const float* temb, const float* R, int ldr, const Geom& g, int C, int mode, const float* part = nullptr) {
     GNParams p;
     p.X = X; p.ldx = ldx; p.Y = Y; p.ldy = ldy; p.gamma = gamma; p.beta = beta; p.rowmask = rowmask; p.temb = temb; p.R = R; p.ldr = ldr;
     p.S = g.S; p.P = g.P; p.T = g.T; p.CG = C / 8; p.mode = mode; p.eps = 1e-5f;
     if (p.CG != 32) return fail(h, "groupnorm kernel expects 32 channels per group, got %d", p.CG);
+    // one utterance whose producer (the conv launched just before) left per-tile statistics: a workgroup per (32 frames, group)
+    if (part && h->gn_stats_tiles > 0 && g.nrows == g.S && h->gn_stats_tiles == (g.nrows + 31) / 32)
+        hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(h->gn_stats_tiles, 8), dim3(256), 0, h->stream, p, part, h->gn_stats_tiles);
     // small batches: 1024 threads per (utterance, group) shorten the per-workgroup latency chain (8 workgroups at B = 1)
-    if (g.nrows / g.S < 32) hipLaunchKernelGGL(groupnorm_mish_kernel<1024>, dim3(g.nrows / g.S, 8), dim3(1024), 0, h->stream, p);
+    else if (g.nrows / g.S < 32) hipLaunchKernelGGL(groupnorm_mish_kernel<1024>, dim3(g.nrows / g.S, 8), dim3(1024), 0, h->stream, p);
     else hipLaunchKernelGGL(groupnorm_mish_kernel<256>, dim3(g.nrows / g.S, 8), dim3(256), 0, h->stream, p);
     HIPCHK(h, hipGetLastError());
     return 0;
@@ -796,6 +812,7 @@ struct EstBufs {
     float *rm0, *rm1, *X0, *state, *A0, *B0, *R0, *H0, *LN0, *QKV0, *ATT0, *FF0, *CAT1, *U1, *F0, *G0, *V0;
     float *A1, *B1, *R1, *H1, *LN1, *QKV1, *ATT1, *FF1, *CAT0, *D1, *D2, *M1, *UU;
     float *tv, *temb_in, *temb_a, *temb_b, *tproj;
+    float *GNP;          // per-tile GroupNorm statistics of a conv_sk32_kernel launch: EV_GN_MAXTILES x 8 groups x {count, mean, M2, -}
     float *ATTP;         // split-key attention partials: EV_ATTN_MAXPARTS x min(rows, EV_ATTN_MAXROWS) x (128 + 4) floats (the levels run one after the other)
     float *C1RMS;        // time-invariant (mu, spk) share of rn[0]'s [block1 conv | res_conv], 512 wide
     float *AR0, *AR1;    // [block1 conv | res_conv] outputs per level, 512 wide
@@ -817,6 +834,7 @@ void plan_est(Bump& b, int B, int Tp, int in_ch, int nsteps, EstBufs& e) {
     const size_t ns = nsteps;
     e.C1RMS = b.take(n0 * 512); e.AR0 = b.take(n0 * 512); e.AR1 = b.take(n1 * 512);
     e.ATTP = b.take(std::min<size_t>(n0, EV_ATTN_MAXROWS) * EV_ATTN_MAXPARTS * (128 + 4));
+    e.GNP = b.take((size_t)EV_GN_MAXTILES * 8 * 4);
     e.tv = b.take(ns); e.temb_in = b.take(ns * in_ch); e.temb_a = b.take(ns * 1024); e.temb_b = b.take(ns * 1024); e.tproj = b.take(ns * 1536);
 }
 
@@ -886,15 +904,15 @@ int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
 // ---------------------------------------------------------------------------
 // estimator forward (decoder.py:363-443).  On entry X0 holds [x*m | mu*m | spk*m].
 // ---------------------------------------------------------------------------
-struct LevelBufs { float *A, *Bf, *R, *H, *LN, *QKV, *ATT, *FF; const float* rm; Geom g; float* AR; float* ATTP; };
+struct LevelBufs { float *A, *Bf, *R, *H, *LN, *QKV, *ATT, *FF; const float* rm; Geom g; float* AR; float* ATTP; float* GNP; };
 inline int g_rows32(const Geom& g) { return (g.nrows + 31) / 32; }
 
 int run_resnet(ev_handle* h, const ResnetW& w, const float* X, int ldx, const LevelBufs& L, const float* temb) {
-    Epi e;
+    Epi e; e.gn_part = L.GNP;
     if (launch_conv(h, w.c1r, X, ldx, L.AR, 512, L.g, e)) return 1;                       // [block1 conv | res_conv]
-    if (launch_gn(h, L.AR, 512, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1)) return 1;
+    if (launch_gn(h, L.AR, 512, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1, L.GNP)) return 1;
     if (launch_conv(h, w.c2, L.Bf, 256, L.A, 256, L.g, e)) return 1;
-    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.AR + 256, 512, L.g, 256, 2);
+    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.AR + 256, 512, L.g, 256, 2, L.GNP);
 }
 
 // rn[0] with the time-invariant input share hoisted out of the Euler loop (see EstimatorW): X = X0 (x in columns [0, n_feats))
@@ -902,9 +920,10 @@ int run_resnet0(ev_handle* h, const EstimatorW& W, const float* X, int ldx, cons
     const ResnetW& w = W.rn[0];
     Epi e;
     { Epi e1; e1.R = C1RMS; e1.ldr = 512; if (launch_conv(h, W.rn0_c1r_x, X, ldx, L.AR, 512, L.g, e1)) return 1; }
-    if (launch_gn(h, L.AR, 512, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1)) return 1;
+    if (launch_gn(h, L.AR, 512, L.Bf, 256, w.g1, w.b1, L.rm, temb, nullptr, 0, L.g, 256, 1)) return 1;   // (c1r adds the hoisted share: no statistics)
+    e.gn_part = L.GNP;
     if (launch_conv(h, w.c2, L.Bf, 256, L.A, 256, L.g, e)) return 1;
-    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.AR + 256, 512, L.g, 256, 2);
+    return launch_gn(h, L.A, 256, L.H, 256, w.g2, w.b2, L.rm, nullptr, L.AR + 256, 512, L.g, 256, 2, L.GNP);
 }
 
 // BasicTransformerBlock (transformer.py:243-316) on L.H; result (masked) -> Z with row stride ldz
@@ -934,8 +953,8 @@ int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z,
 int run_estimator(ev_handle* h, EstBufs& b, int step, float dt, bool euler) {
     const EstimatorW& w = h->est;
     const int heads = h->dims.heads;
-    LevelBufs L0{b.A0, b.B0, b.R0, b.H0, b.LN0, b.QKV0, b.ATT0, b.FF0, b.rm0, b.g0, b.AR0, b.ATTP};
-    LevelBufs L1{b.A1, b.B1, b.R1, b.H1, b.LN1, b.QKV1, b.ATT1, b.FF1, b.rm1, b.g1, b.AR1, b.ATTP};
+    LevelBufs L0{b.A0, b.B0, b.R0, b.H0, b.LN0, b.QKV0, b.ATT0, b.FF0, b.rm0, b.g0, b.AR0, b.ATTP, b.GNP};
+    LevelBufs L1{b.A1, b.B1, b.R1, b.H1, b.LN1, b.QKV1, b.ATT1, b.FF1, b.rm1, b.g1, b.AR1, b.ATTP, b.GNP};
     const float* tp = b.tproj + (size_t)step * 1536;
     // down 0 @T
     if (run_resnet0(h, w, b.X0, w.in_ch, L0, tp + 0 * 256, b.C1RMS)) return 1;

@@ -57,6 +57,8 @@ struct ConvParams {
     float* Y2; int ldy2;                    // optional second output = v * rowmask
     int ktaps_n, plane_bytes, koff0, kdoff; // dense layers (every tap in every tile) with evenly spaced taps: tap i = {i * plane_bytes,
                                             // koff0 + i * kdoff} — conv_gemm_sk_kernel derives the list from the kernel arguments instead of fetching it
+    float* gn_part;                         // conv_sk32_kernel, one utterance: per (32-row tile, 32-channel group) {count, mean, M2} of the stored
+                                            // tile — the GroupNorm statistics of the layer that follows (groupnorm_apply_kernel), or null
     int kstack_mt, kstack_tap;              // stacked layers (a k-tap conv over a 1x1 conv along Cout): 32-channel tiles >= kstack_mt carry the
                                             // single tap kstack_tap, the tiles below it all ntaps (0 = not such a layer); conv_sk32_kernel only
     int sk_kb;                              // conv_gemm_sk_kernel: k-chunks per staging round
@@ -904,6 +906,7 @@ __global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvPa
 //   2-D grid (no tile-index division).
 // Same operands, products and summation order as conv_gemm_sk_kernel<8, false, LEAN, 1>.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v);   // (defined with the normalisation kernels below)
 template <int LEAN>
 __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
     constexpr int KS = 8, NTHR = 512, MAXPASS = 16, NPRE = 4;
@@ -913,7 +916,7 @@ __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
                       "+s"(p.P), "+s"(p.T), "+s"(p.ntaps), "+s"(p.halo_lo), "+s"(p.halo_hi));
     asm volatile("" : "+s"(p.act), "+s"(p.act_slope), "+s"(p.act_a), "+s"(p.act_b), "+s"(p.mask1), "+s"(p.R), "+s"(p.ldr), "+s"(p.accum), "+s"(p.div3),
                       "+s"(p.act2_lrelu), "+s"(p.act2_slope), "+s"(p.mask2), "+s"(p.rowmask), "+s"(p.plane_bytes), "+s"(p.koff0));
-    asm volatile("" : "+s"(p.kdoff), "+s"(p.stamps), "+s"(p.dbg), "+s"(p.kstack_mt), "+s"(p.kstack_tap));
+    asm volatile("" : "+s"(p.kdoff), "+s"(p.stamps), "+s"(p.dbg), "+s"(p.kstack_mt), "+s"(p.kstack_tap), "+s"(p.gn_part));
     const int tid = threadIdx.x, lane = tid & 63;
     const int ks = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -1042,6 +1045,25 @@ __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
         for (int k = 0; k < KS - 1; ++k)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accs[0][0][r] += red[(k * 16 + r) * 64 + lane];
+        if (p.gn_part && (p.kstack_mt == 0 || (int)blockIdx.x < p.kstack_mt)) {
+            // (host: one utterance, plain epilogue — the tile is stored as it stands) statistics of this (32 frames x one group)
+            // tile over its frames inside [0, T): lane = frame li, 16 of the group's channels per lane half
+            const int t = n0 + li - p.P;
+            const bool valid = t >= 0 && t < p.T;
+            float sm = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm += accs[0][0][r];
+            const float cnt = wave_sum(valid ? 16.f : 0.f);
+            const float mean = cnt > 0.f ? wave_sum(valid ? sm : 0.f) / cnt : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float d = accs[0][0][r] - mean; q += d * d; }
+            q = wave_sum(valid ? q : 0.f);
+            if (lane == 0) {
+                f32x4 o = {cnt, mean, q, 0.f};
+                *(f32x4*)(p.gn_part + ((size_t)blockIdx.y * 8 + blockIdx.x) * 4) = o;
+            }
+        }
     };
     conv_epilogue_lean<1, 1, LEAN>(p, accs, smem, m0, n0, lane, -0x7fffffff, 0x7fffffff, reduce);
     if ((p.dbg & 16) && tid == 0) p.stamps[4 * wg + 3] = __builtin_amdgcn_s_memrealtime();
@@ -1368,6 +1390,59 @@ __global__ __launch_bounds__(NTHR) void groupnorm_mish_kernel(const GNParams p) 
     } else {
         for (int t = r0; t < p.T; t += rpp) apply(t, *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase));
     }
+}
+
+// groupnorm_apply_kernel: GroupNorm + Mish of ONE utterance whose per-tile statistics the producing conv_sk32_kernel left in
+// `part` ([row tiles of 32][8 groups]{count, mean, M2}).  groupnorm_mish_kernel is one workgroup per (utterance, group): at batch 1
+// eight CUs evaluate all T x 256 Mish (7.7 us, 130 launches per decode).  Here a workgroup is one (32-frame tile, group): every
+// thread merges the tiles' statistics in ascending tile order (Chan et al.'s pairwise update — deterministic, and at least as
+// accurate as the two-pass sums), then normalises its four channels of one frame.  Same epilogue modes as groupnorm_mish_kernel.
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const GNParams p, const float* part, int ntiles) {
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int t = blockIdx.x * 32 + (tid >> 3) - p.P, c4 = (tid & 7) * 4;
+    const int cbase = g * 32 + c4;
+    const bool live = t >= 0 && t < p.T;
+    const size_t n = (size_t)p.P + (live ? t : 0);
+    // every operand is requested before the first use: one memory round trip for the whole workgroup
+    const f32x4 v = *(const f32x4*)(p.X + n * p.ldx + cbase);
+    const f32x4 ga = *(const f32x4*)(p.gamma + cbase), be = *(const f32x4*)(p.beta + cbase);
+    f32x4 te = {0.f, 0.f, 0.f, 0.f}, rr = te;
+    if (p.mode == 1) te = *(const f32x4*)(p.temb + cbase);
+    if (p.mode == 2) rr = *(const f32x4*)(p.R + n * p.ldr + cbase);
+    const float m = p.rowmask[n];
+    // tile j's {count, mean, M2} on lane j (64 tiles per round), merged in ascending order through v_readlane
+    float na = 0.f, mean = 0.f, m2 = 0.f;
+    for (int j0 = 0; j0 < ntiles; j0 += 64) {
+        int pn = 0, pm = 0, pq = 0;
+        if (j0 + lane < ntiles) {
+            const int* pp = (const int*)(part + ((size_t)(j0 + lane) * 8 + g) * 4);
+            pn = pp[0]; pm = pp[1]; pq = pp[2];
+        }
+        const int nj = ntiles - j0 < 64 ? ntiles - j0 : 64;
+        for (int j = 0; j < nj; ++j) {
+            const float nb = __int_as_float(__builtin_amdgcn_readlane(pn, j));
+            const float mb = __int_as_float(__builtin_amdgcn_readlane(pm, j));
+            const float qb = __int_as_float(__builtin_amdgcn_readlane(pq, j));
+            if (nb > 0.f) {                      // (wave-uniform)
+                const float nn = na + nb, d = mb - mean, w = nb / nn;
+                mean += d * w;
+                m2 += qb + d * d * na * w;
+                na = nn;
+            }
+        }
+    }
+    if (!live) return;
+    const float rstd = 1.0f / sqrtf(m2 / na + p.eps);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float y = (v[e] - mean) * rstd * ga[e] + be[e];
+        y = ev_mish(y) * m;
+        if (p.mode == 1) y = (y + te[e]) * m;
+        o[e] = y;
+    }
+    if (p.mode == 2) { o[0] += rr[0]; o[1] += rr[1]; o[2] += rr[2]; o[3] += rr[3]; }
+    *(f32x4*)(p.Y + n * p.ldy + cbase) = o;
 }
 
 // ---------------------------------------------------------------------------

@@ -22,11 +22,12 @@ from emojivoice_amd.matcha_tts import MatchaTTS
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(7)
 B, T = 3, 44
+if len(sys.argv) > 2 and sys.argv[2] == "b1": B, T = 1, 100
 m = MatchaTTS(W.synthetic_matcha_state(), device=dev)
 voc = Generator(AttrDict(v1)).to(dev); voc.load_state_dict(W.synthetic_hifigan_state())
 mu = torch.randn(B, 80, T, generator=g).to(dev); z = (torch.randn(B, 80, T, generator=g) * 0.667).to(dev)
-lengths = torch.tensor([44, 31, 17], dtype=torch.int32).to(dev)
-spk = m._sd["spk_emb.weight"][torch.tensor([1, 5, 9], device=dev)]
+lengths = torch.tensor([44, 31, 17] if B == 3 else [T], dtype=torch.int32).to(dev)
+spk = m._sd["spk_emb.weight"][torch.tensor([1, 5, 9][:B], device=dev)]
 mel = m.engine.cfm_decode(mu, lengths, spk, z, 4, m.mel_std, m.mel_mean)
 wav = voc(mel)
 torch.save({"mel": mel.cpu(), "wav": wav.cpu()}, sys.argv[1])
@@ -36,11 +37,15 @@ VARIANTS = [{"EV_KB": "2"}, {"EV_NO_LEAN": "1"}, {"EV_FUSE_PAIRS": "0"}, {"EV_FO
             {"EV_FORCE_CFG": "4"}, {"EV_FUSE_MLP_MIN": "1"}, {"EV_FUSE_MLP": "0"}, {"EV_NO_ATTN_SK": "1"}]
 
 
-def _run(tmp_path, name, extra):
+# the single-utterance builds: conv_sk32_kernel, per-tile GroupNorm statistics + groupnorm_apply_kernel, split-key attention
+B1_VARIANTS = [{"EV_NO_GN_STATS": "1"}, {"EV_NO_SK32_LEAN": "1"}, {"EV_ATTN_TPW": "1"}, {"EV_ATTN_TPW": "3"}, {"EV_NO_ATTN_SK": "1"}, {"EV_NO_SK": "1"}]
+
+
+def _run(tmp_path, name, extra, shape="b3"):
     out = tmp_path / f"{name}.pt"
     env = dict(os.environ)
     env.update(extra)
-    r = subprocess.run([sys.executable, "-c", CHILD, str(out)], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", CHILD, str(out), shape], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     import torch
 
@@ -55,3 +60,15 @@ def test_kernel_variants_agree(tmp_path):
         dmel = float((got["mel"] - ref["mel"]).abs().max())
         dwav = float((got["wav"] - ref["wav"]).abs().max())
         assert dmel <= 2e-5 and dwav <= 2e-5, (extra, dmel, dwav)
+
+
+def test_batch1_variants_agree(tmp_path):
+    """One utterance takes builds of its own (far fewer workgroups than CUs): they agree with the general ones.  The per-tile
+    GroupNorm statistics are merged pairwise instead of summed in two passes: a few 1e-6 on the mel."""
+    ref = _run(tmp_path, "b1_default", {}, "b1")
+    assert ref["mel"].shape == (1, 80, 100)
+    for i, extra in enumerate(B1_VARIANTS):
+        got = _run(tmp_path, f"b1_v{i}", extra, "b1")
+        dmel = float((got["mel"] - ref["mel"]).abs().max())
+        dwav = float((got["wav"] - ref["wav"]).abs().max())
+        assert dmel <= 2e-5 and dwav <= 5e-5, (extra, dmel, dwav)
