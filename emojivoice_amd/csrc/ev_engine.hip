@@ -131,6 +131,13 @@ struct ev_handle {
     struct ProfRec { int kind, Cin, Cout, ntaps, nrows, cfg, lean; double flops; };
     std::vector<ProfRec> prof_recs;   // one per timed launch (EV_PROFILE_DUMP=<file> writes the per-shape table)
     hipStream_t stream = nullptr;
+    // HiFi-GAN at small batch: the three ResBlock1 chains of an MRF level (kernel sizes 3 / 7 / 11, models.py:186-192) run on
+    // three streams (the caller's + two of the handle's), ordered by events where they join the running sum
+    hipStream_t mrf_stream[2] = {nullptr, nullptr};
+    hipEvent_t mrf_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int mrf_max_frames = 16384;     // EV_MRF_STREAMS_MAX=<B*T mel frames>: calls up to this size use the three streams (0 = never).  Six more scratch
+                                    // tensors per level; at batch 64 x 516 frames (21 GB) the two-stage pipeline of bench.py already fills the gaps:
+                                    // -1.4 % on the vocoder alone, +0.6 % on the pipelined step
 };
 
 namespace {
@@ -842,9 +849,11 @@ struct VocBufs {
     Geom g[5];
     float *M0, *C0;
     float *U[5], *XS[5], *T1[5], *Pa[5], *Pb[5];
+    float *T1x[2][5], *Pax[2][5], *Pbx[2][5];   // scratch of the second and third ResBlock1 chain (three-stream MRF; null otherwise)
+    struct { float* p; int C, l; } zl[64]; int nz = 0;   // every tensor of the plan (for zero_pads_kernel)
 };
 
-void plan_voc(Bump& b, int B, int T, const int* ch, VocBufs& v) {
+void plan_voc(Bump& b, int B, int T, const int* ch, VocBufs& v, bool mrf_streams = false) {
     const int rates[4] = {8, 8, 2, 2};
     int Tl = T, Pl = 4;
     v.g[0] = {B * (Tl + 2 * Pl), Tl + 2 * Pl, Pl, Tl};
@@ -852,22 +861,30 @@ void plan_voc(Bump& b, int B, int T, const int* ch, VocBufs& v) {
         Tl *= rates[l - 1]; Pl *= rates[l - 1];
         v.g[l] = {B * (Tl + 2 * Pl), Tl + 2 * Pl, Pl, Tl};
     }
-    v.M0 = b.take((size_t)v.g[0].nrows * 80);
-    v.C0 = b.take((size_t)v.g[0].nrows * ch[0]);
+    v.nz = 0;
+    auto take = [&](size_t n, int C, int l) { float* q = b.take(n); v.zl[v.nz].p = q; v.zl[v.nz].C = C; v.zl[v.nz].l = l; ++v.nz; return q; };
+    v.M0 = take((size_t)v.g[0].nrows * 80, 80, 0);
+    v.C0 = take((size_t)v.g[0].nrows * ch[0], ch[0], 0);
     for (int l = 1; l <= 4; ++l) {
         const size_t n = (size_t)v.g[l].nrows * ch[l];
-        v.U[l] = b.take(n); v.XS[l] = b.take(n); v.T1[l] = b.take(n); v.Pa[l] = b.take(n); v.Pb[l] = b.take(n);
+        v.U[l] = take(n, ch[l], l); v.XS[l] = take(n, ch[l], l); v.T1[l] = take(n, ch[l], l); v.Pa[l] = take(n, ch[l], l); v.Pb[l] = take(n, ch[l], l);
+        for (int c = 0; c < 2; ++c) {
+            v.T1x[c][l] = mrf_streams ? take(n, ch[l], l) : nullptr; v.Pax[c][l] = mrf_streams ? take(n, ch[l], l) : nullptr;
+            v.Pbx[c][l] = mrf_streams ? take(n, ch[l], l) : nullptr;
+        }
     }
 }
+inline bool mrf_streams_for(const ev_handle* h, int B, int Tv) { return h->mrf_max_frames > 0 && (long)B * Tv <= h->mrf_max_frames; }
 
 
-size_t plan_all(ev_handle* h, char* base, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
+size_t plan_all(ev_handle* h, char* base, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb, size_t* voc_off = nullptr) {
     Bump b{base, 0, 0};
     EstBufs e; VocBufs v;
     if (Tp > 0) plan_est(b, B, Tp, h->est.loaded ? h->est.in_ch : 2 * h->dims.n_feats + h->dims.spk_emb_dim, h->max_steps, e);
+    if (voc_off) *voc_off = b.off;
     if (Tv > 0) {
         int ch[5] = {512, 256, 128, 64, 32};
-        plan_voc(b, B, Tv, h->voc.loaded ? h->voc.ch : ch, v);
+        plan_voc(b, B, Tv, h->voc.loaded ? h->voc.ch : ch, v, mrf_streams_for(h, B, Tv));
     }
     if (eb) *eb = e;
     if (vb) *vb = v;
@@ -893,11 +910,32 @@ int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
         h->ws_bytes = need;
         rezero = true;
     }
+    size_t voc_off = 0;
+    VocBufs vplan;
+    plan_all(h, h->ws, B, Tp, Tv, eb, &vplan, &voc_off);
+    if (vb) *vb = vplan;
     if (rezero) {
-        HIPCHK(h, hipMemsetAsync(h->ws, 0, need, h->stream));
+        // the estimator's part is zeroed whole (small); of the vocoder's tensors — 0.3-1.1 GB for one streaming utterance — only
+        // the pad rows, which is all the convolutions need (zero_pads_kernel)
+        static const bool full_zero = getenv("EV_FULL_REZERO") != nullptr;
+        const size_t zbytes = (full_zero || Tv <= 0) ? need : voc_off;
+        if (zbytes) HIPCHK(h, hipMemsetAsync(h->ws, 0, zbytes, h->stream));
+        if (!full_zero && Tv > 0 && vplan.nz > 0) {
+            ZeroPadParams zp;
+            memset(&zp, 0, sizeof zp);
+            zp.B = B; zp.n = vplan.nz;
+            for (int k = 0; k < vplan.nz; ++k) { zp.p[k] = vplan.zl[k].p; zp.C[k] = vplan.zl[k].C; zp.lvl[k] = vplan.zl[k].l; }
+            long most = 0;
+            for (int l = 0; l < 5; ++l) {
+                zp.S[l] = vplan.g[l].S; zp.P[l] = vplan.g[l].P; zp.T[l] = vplan.g[l].T;
+            }
+            for (int k = 0; k < vplan.nz; ++k) most = std::max(most, (long)B * (zp.S[zp.lvl[k]] - zp.T[zp.lvl[k]]) * (zp.C[k] / 4));
+            const unsigned gx = (unsigned)std::min<long>((most + 255) / 256, 512);
+            hipLaunchKernelGGL(zero_pads_kernel, dim3(gx ? gx : 1, vplan.nz), dim3(256), 0, h->stream, zp);
+            HIPCHK(h, hipGetLastError());
+        }
         h->ws_B = B; h->ws_Tp = Tp; h->ws_Tv = Tv;
     }
-    plan_all(h, h->ws, B, Tp, Tv, eb, vb);
     return 0;
 }
 
@@ -1254,6 +1292,7 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     { const char* fp = getenv("EV_FUSE128"); if (fp && *fp) h->fuse128 = atoi(fp); }
     { const char* fp = getenv("EV_FUSE_MLP"); if (fp && *fp == '0') h->fuse_mlp = false; }
     { const char* fp = getenv("EV_FUSE_MLP_MIN"); if (fp && *fp) h->fuse_mlp_min_tiles = atoi(fp); }
+    { const char* fp = getenv("EV_MRF_STREAMS_MAX"); if (fp && *fp) h->mrf_max_frames = atoi(fp); }
     // the shipped decoder configuration (configs/model/decoder/default.yaml: 2 heads x 64) is the only one the workspace
     // plan and the transformer launch sequence are laid out for
     if (dims->n_feats != 80 || dims->channels != 256 || dims->head_dim != 64 || dims->heads != 2) {
@@ -1275,6 +1314,8 @@ void ev_destroy(ev_handle* h) {
     if (h->dn_ws.p) hipFree(h->dn_ws.p);
     if (h->bad_ids_host) hipHostFree(h->bad_ids_host);
     for (int i = 0; i < 2; ++i) { if (h->temb_ev[i]) hipEventDestroy(h->temb_ev[i]); if (h->temb_host[i]) hipHostFree(h->temb_host[i]); }
+    for (int i = 0; i < 2; ++i) if (h->mrf_stream[i]) hipStreamDestroy(h->mrf_stream[i]);
+    for (int i = 0; i < 4; ++i) if (h->mrf_ev[i]) hipEventDestroy(h->mrf_ev[i]);
     delete h;
 }
 
@@ -1664,16 +1705,40 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
     }
     const float* xin = v.C0;
     int cin = w.ch[0];
+    // The three ResBlock1 chains of a level are independent until they join the running sum, so they go to three streams and fill
+    // each other's gaps: a streaming utterance is 1-4 workgroups per CU and launch, every launch a lock-step stage -> MFMA ->
+    // epilogue sequence with a quantisation tail (batch 1: -13 % at T = 516; batch 16: -3 %).  The joins keep the serial order
+    // (x3 + x7 + x11) / 3.
+    const bool ms = mrf_streams_for(h, B, T) && !h->prof && v.Pax[0][1] != nullptr;
+    if (ms && !h->mrf_stream[0]) {
+        for (int c = 0; c < 2; ++c) HIPCHK(h, hipStreamCreateWithFlags(&h->mrf_stream[c], hipStreamNonBlocking));
+        for (int c = 0; c < 4; ++c) HIPCHK(h, hipEventCreateWithFlags(&h->mrf_ev[c], hipEventDisableTiming));
+    }
+    // Work queued on the two extra streams BEHIND a busy caller's stream slows that stream down: with barrier packets pending in
+    // two more hardware queues every dispatch of the caller's stream took ~5 us longer (a 6.3 ms CFM decode in front of the
+    // vocoder became 8.4 ms; tools/stream_split.py).  So the call first waits for the caller's stream to drain — the host has
+    // nothing else to enqueue for this utterance anyway — and only then fans out.
+    if (ms) HIPCHK(h, hipStreamSynchronize(h->stream));
+    hipStream_t s0 = h->stream;
+    struct StreamGuard { ev_handle* h; hipStream_t s; ~StreamGuard() { h->stream = s; } } guard{h, s0};
     for (int i = 0; i < 4; ++i) {
         const int l = i + 1, C = w.ch[l], s = w.ups[i].Cout / C;
         {   // transposed conv: input frames of level l-1 -> view rows of s output frames each
             Epi e;
             if (launch_conv(h, w.ups[i], xin, cin, v.U[l], s * C, v.g[l - 1], e)) return 1;
         }
+        if (ms) {
+            HIPCHK(h, hipEventRecord(h->mrf_ev[3], s0));
+            for (int c = 0; c < 2; ++c) HIPCHK(h, hipStreamWaitEvent(h->mrf_stream[c], h->mrf_ev[3], 0));
+        }
         for (int j = 0; j < 3; ++j) {
             const float* x = v.U[l];
-            float* pp[2] = {v.Pa[l], v.Pb[l]};
+            const bool own = ms && j > 0;                      // chain j on its own stream with its own scratch
+            h->stream = own ? h->mrf_stream[j - 1] : s0;
+            float* pp[2] = {own ? v.Pax[j - 1][l] : v.Pa[l], own ? v.Pbx[j - 1][l] : v.Pb[l]};
+            float* t1 = own ? v.T1x[j - 1][l] : v.T1[l];
             for (int mm = 0; mm < 3; ++mm) {
+                if (ms && mm == 2 && j > 0) HIPCHK(h, hipStreamWaitEvent(h->stream, h->mrf_ev[j - 1], 0));   // the sum so far is in XS
                 Epi e2; e2.R = x; e2.ldr = C;                                          // c2 + x
                 float* y = pp[mm & 1];
                 if (mm == 2) {   // resblock output joins the running mean over the 3 kernel sizes (models.py:186-192)
@@ -1686,12 +1751,15 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
                     if (launch_pair(h, w.c1[i * 3 + j][mm], w.c2[i * 3 + j][mm], x, y, C, v.g[l], e2)) return 1;
                 } else {
                     Epi e1; e1.pro_slope = 0.1f; e1.act = ACT_LRELU; e1.act_slope = 0.1f;   // lrelu -> c1 -> lrelu
-                    if (launch_conv(h, w.c1[i * 3 + j][mm], x, C, v.T1[l], C, v.g[l], e1)) return 1;
-                    if (launch_conv(h, w.c2[i * 3 + j][mm], v.T1[l], C, y, C, v.g[l], e2)) return 1;
+                    if (launch_conv(h, w.c1[i * 3 + j][mm], x, C, t1, C, v.g[l], e1)) return 1;
+                    if (launch_conv(h, w.c2[i * 3 + j][mm], t1, C, y, C, v.g[l], e2)) return 1;
                 }
+                if (ms && mm == 2) HIPCHK(h, hipEventRecord(h->mrf_ev[j], h->stream));
                 x = y;
             }
         }
+        h->stream = s0;
+        if (ms) HIPCHK(h, hipStreamWaitEvent(s0, h->mrf_ev[2], 0));   // (chain 2's join waited for chain 1's, which waited for chain 0's)
         xin = v.XS[l];
         cin = C;
     }

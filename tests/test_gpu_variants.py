@@ -1,5 +1,6 @@
 """The kernel A/B switches (tile configuration, two-chunk staging, generic instead of lean epilogue, unfused resblock pairs,
-fused LayerNorm + QKV / feed-forward kernels forced on at a small batch or switched off, split-key attention switched off)
+fused LayerNorm + QKV / feed-forward kernels forced on at a small batch or switched off, split-key attention switched off,
+the three ResBlock1 chains of an MRF level on one stream instead of three, the workspace zeroed whole instead of its pad rows)
 must not change results: every build accumulates in the same (chunk, tap, k-group) order, so the variants agree with the
 default path to fp32 rounding of the epilogue (bias added before vs after the K loop).  The switches are read once per
 process, hence one child process per variant."""
@@ -34,7 +35,8 @@ torch.save({"mel": mel.cpu(), "wav": wav.cpu()}, sys.argv[1])
 """ % REPO
 
 VARIANTS = [{"EV_KB": "2"}, {"EV_NO_LEAN": "1"}, {"EV_FUSE_PAIRS": "0"}, {"EV_FORCE_CFG": "0"}, {"EV_FORCE_CFG": "5"}, {"EV_FORCE_CFG": "6"},
-            {"EV_FORCE_CFG": "4"}, {"EV_FUSE_MLP_MIN": "1"}, {"EV_FUSE_MLP": "0"}, {"EV_NO_ATTN_SK": "1"}]
+            {"EV_FORCE_CFG": "4"}, {"EV_FUSE_MLP_MIN": "1"}, {"EV_FUSE_MLP": "0"}, {"EV_NO_ATTN_SK": "1"},
+            {"EV_MRF_STREAMS_MAX": "0"}, {"EV_FULL_REZERO": "1"}]
 
 
 # the single-utterance builds: conv_sk32_kernel, per-tile GroupNorm statistics + groupnorm_apply_kernel, split-key attention
