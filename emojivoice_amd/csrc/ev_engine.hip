@@ -518,8 +518,9 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         if (!no_sk && (cfg == 6 || cfg == 8) && wg64 <= 192 && (L.Kpad / EV_BK) * L.ntaps >= 8) cfg = 9;
         // (a short K loop gains nothing from the split, but the 32 x 32 build for it is the instruction-lean conv_sk32_kernel)
         if (!no_sk && (cfg == 6 || cfg == 8) && wg64 <= 96 && L.Kpad == 128 && L.Cin == 128 && !L.sparse_taps) cfg = 9;
-        // ... and when even those are only a few dozen workgroups: 32 x 32 tiles, four times as many CUs (EV_SK32_MAX, A/B)
-        static const int sk32_max = getenv("EV_SK32_MAX") ? atoi(getenv("EV_SK32_MAX")) : 96;
+        // ... as 32 x 32 tiles on four times as many CUs (EV_SK32_MAX, A/B: 96 while the build held one workgroup per CU; since
+        // conv_sk32_kernel fits two — 119 VGPRs — launches of up to 512 such tiles are still one round: 192; config-5 mean -1.9 %, p99 -4.5 %)
+        static const int sk32_max = getenv("EV_SK32_MAX") ? atoi(getenv("EV_SK32_MAX")) : 192;
         if (cfg == 9 && wg64 <= sk32_max && L.Cout >= 32) cfg = 19;
     }
     {   // A/B override for the stacked sparse-tap layers only (a 3-tap conv over a 1x1 conv): EV_SPARSE_CFG=<cfg>[,<min rows>]

@@ -908,8 +908,8 @@ __global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvPa
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v);   // (defined with the normalisation kernels below)
 template <int LEAN>
-__global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
-    constexpr int KS = 8, NTHR = 512, MAXPASS = 16, NPRE = 4;
+__global__ __launch_bounds__(512, 4) void conv_sk32_kernel(const ConvParams pk) {
+    constexpr int KS = 8, NTHR = 512, MAXPASS = 16, NPRE = 3;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     ConvParams p = pk;          // one batch of scalar loads, opaque afterwards (see conv_gemm_sk_kernel)
     asm volatile("" : "+s"(p.X), "+s"(p.ldx), "+s"(p.W), "+s"(p.Kpad), "+s"(p.bias), "+s"(p.Y), "+s"(p.ldy), "+s"(p.Cout), "+s"(p.nrows), "+s"(p.S),
@@ -951,12 +951,6 @@ __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
             if (++ti == nact) { ti = 0; cn += KS; }
         }
     }
-    f32x4 bq[4];
-    {
-        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (ks == 0 && p.bias) ? p.Cout * 4 : 0, 0x00020000);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB, (unsigned)(m0 + 8 * g + 4 * lh) * 4u, 0);
-    }
     // ---- X tile: thread = (row tid >> f4_log2 [+ adv_r per pass], float4 column tid & (f4 - 1)); rows outside the tensor read
     // an out-of-range offset (the descriptor returns 0): no branches around the loads
     {
@@ -982,6 +976,14 @@ __global__ __launch_bounds__(512) void conv_sk32_kernel(const ConvParams pk) {
                 dst += dstep;
             }
         }
+    }
+    // bias (requested once the staging registers are free: the kernel stays within 128 VGPRs = two workgroups per CU, so a launch
+    // of 257-512 tiles is still one round)
+    f32x4 bq[4];
+    {
+        const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, (ks == 0 && p.bias) ? p.Cout * 4 : 0, 0x00020000);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB, (unsigned)(m0 + 8 * g + 4 * lh) * 4u, 0);
     }
     ev_lds_barrier();
     if ((p.dbg & 16) && tid == 0) p.stamps[4 * wg + 1] = __builtin_amdgcn_s_memrealtime();
