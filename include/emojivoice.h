@@ -117,7 +117,10 @@ int ev_text_encoder_status(ev_handle *h, void *stream);
 int ev_align(ev_handle *h, const float *d_wceil, const float *d_mu_x, const int32_t *d_xlen, const int64_t *d_ylen,
              int B, int Tx, int Tp, float *d_mu_y, float *d_attn, void *stream);
 
-/* HiFi-GAN V1 generator: d_mel (B, 80, T) -> d_wav (B, 256*T), tanh output, no clamp/denoiser. */
+/* HiFi-GAN V1 generator: d_mel (B, 80, T) -> d_wav (B, 256*T), tanh output, no clamp/denoiser.
+ * Calls of B*T <= 16384 mel frames (EV_MRF_STREAMS_MAX) first wait for `stream` to drain on the host, then run the three
+ * ResBlock1 chains of each level on `stream` and two streams of the handle, joined back into `stream` by events before the
+ * call returns: the result is ordered on `stream` like that of any other call.  Such a call is not graph-capturable. */
 int ev_hifigan(ev_handle *h, const float *d_mel, int B, int T, float *d_wav, void *stream);
 
 /* Denoiser stage that every reference caller applies to the vocoder output (hifigan/denoiser.py:10-64; cli.py:121-126,
