@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Conv-kernel microbenchmark / ablation on the GPU box: per HiFi-GAN level and estimator shape, TFLOP/s of
-conv_gemm_kernel for tile configs and ablation bits (1: no X loads, 2: no A loads, 4: no epilogue)."""
+conv_gemm_kernel for tile configs and ablation bits (1: no X loads, 2: no A loads, 4: no epilogue; 16: per-workgroup
+s_memrealtime stamps {start, staging done, K loop done, end}, with 1024 / 2048 moving the second stamp inside the staging of the
+small-launch build; 128: no residual; 512: no prologue activation = the estimator's layers, which is what conv_sk32_kernel takes).
+EST_B=<batch> sets the batch of the "est" shapes (1 = a streaming decode), SHAPES=<prefixes> selects rows."""
 import ctypes as C
 import os
 import sys

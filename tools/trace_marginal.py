@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Per-kernel marginal time on an in-order stream from a rocprofv3 --kernel-trace CSV: for the last N dispatches, the gap from the
+previous kernel's end to this kernel's end is attributed to this kernel (what the launch adds to the wall time), next to its own
+duration.    python tools/trace_marginal.py <rocprof output dir> <last N dispatches> <rows to print>"""
 import csv,glob,collections,sys
 f=glob.glob(sys.argv[1]+"/*/*kernel_trace.csv")[0]
 rows=list(csv.DictReader(open(f)))
