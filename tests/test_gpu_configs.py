@@ -381,3 +381,32 @@ dist.destroy_process_group(); print("rccl ok")
 '''
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ))
     assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_geometry_changes_leave_no_stale_rows(model, vocoder):
+    """A change of (B, T) re-plans the workspace and clears only what the new geometry needs (pad rows of the vocoder's tensors,
+    the estimator's part whole): results must not depend on what an earlier, differently shaped call left behind."""
+    g = torch.Generator().manual_seed(5)
+    dev = model.device
+
+    def voc_call(B, T, seed):
+        gg = torch.Generator().manual_seed(seed)
+        return vocoder((torch.randn(B, 80, T, generator=gg) * 2 - 5).to(dev)).cpu()
+
+    def cfm_call(B, T, seed):
+        gg = torch.Generator().manual_seed(seed)
+        mu, z = torch.randn(B, 80, T, generator=gg).to(dev), torch.randn(B, 80, T, generator=gg).to(dev)
+        lengths = torch.tensor([T] + [max(1, T - 3 * i) for i in range(1, B)], device=dev)
+        spk = model._sd["spk_emb.weight"][torch.arange(B, device=dev)]
+        return model.engine.cfm_decode(mu, lengths, spk, z, 2).cpu()
+
+    for call in (voc_call, cfm_call):
+        first = {}
+        shapes = [(1, 36, 1), (2, 20, 2), (1, 100, 3), (3, 12, 4), (1, 36, 1), (1, 8, 5), (2, 20, 2), (1, 100, 3), (1, 8, 5), (3, 12, 4)]
+        for B, T, seed in shapes:                      # every shape is visited twice, with other shapes in between
+            out = call(B, T, seed)
+            assert torch.isfinite(out).all()
+            if (B, T) in first:
+                assert torch.equal(out, first[(B, T)]), (call.__name__, B, T)
+            else:
+                first[(B, T)] = out
