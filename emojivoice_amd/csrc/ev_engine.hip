@@ -1051,18 +1051,20 @@ int run_time_mlp(ev_handle* h, EstBufs& b, const std::vector<float>& ts) {
     {   // staged through a two-slot pinned ring owned by the handle: no host/stream synchronisation per call, so a caller
         // that pipelines consecutive batches on two streams (emojivoice_amd/pipeline.py) keeps enqueueing ahead of the GPU
         const size_t bytes = emb.size() * sizeof(float);
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        const bool capturing = h->stream && hipStreamIsCapturing(h->stream, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive;
         const int slot = (h->temb_slot ^= 1);
         if (h->temb_cap[slot] < bytes) {
             if (h->temb_host[slot]) { HIPCHK(h, hipEventSynchronize(h->temb_ev[slot])); HIPCHK(h, hipHostFree(h->temb_host[slot])); }
             HIPCHK(h, hipHostMalloc((void**)&h->temb_host[slot], bytes, hipHostMallocDefault));
             h->temb_cap[slot] = bytes;
             if (!h->temb_ev[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->temb_ev[slot], hipEventDisableTiming));
-        } else {
+        } else if (!capturing) {
             HIPCHK(h, hipEventSynchronize(h->temb_ev[slot]));   // the copy issued two calls ago has read this slot
         }
         memcpy(h->temb_host[slot], emb.data(), bytes);
         HIPCHK(h, hipMemcpyAsync(b.temb_in, h->temb_host[slot], bytes, hipMemcpyHostToDevice, h->stream));
-        HIPCHK(h, hipEventRecord(h->temb_ev[slot], h->stream));
+        if (!capturing) HIPCHK(h, hipEventRecord(h->temb_ev[slot], h->stream));
     }
     Geom gt{nt, nt, 0, nt};
     Epi e1; e1.act = ACT_SILU;
