@@ -24,7 +24,8 @@
  *     duration of the call and all work is enqueued asynchronously on `stream`
  *     (a hipStream_t passed as void*; NULL = the default stream).
  *   - The handle owns the re-laid-out weights and a workspace that grows on demand
- *     (growth = hipMalloc, so the first call at a new (B,T) is not graph-capturable).
+ *     (growth = hipMalloc, so the first call at a new (B,T) is not graph-capturable; later ev_cfm_decode calls at that shape
+ *     are: they enqueue kernels and one pinned-memory copy and never wait on the host — tests/test_gpu_configs.py).
  *   - Layout at the boundary is the reference's: mel-like tensors are (B, 80, T)
  *     channel-major contiguous; waveforms are (B, 256*T) contiguous.
  *   - Every function returns 0 on success, non-zero on failure; the message is
