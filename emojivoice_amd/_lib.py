@@ -22,7 +22,7 @@ EXPORTS = [
     "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder", "ev_load_text_encoder", "ev_text_encoder",
     "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read",
-    "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention", "ev_op_ln_mlp",
+    "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention", "ev_op_ln_mlp", "ev_set_mrf_streams_max",
 ]
 
 
@@ -76,6 +76,8 @@ def load_library() -> C.CDLL:
     lib.ev_last_error.restype = C.c_char_p
     for f in (lib.ev_load_estimator, lib.ev_load_vocoder, lib.ev_load_text_encoder):
         f.argtypes = [vp, vp, C.POINTER(ev_tensor_index), u64]
+    lib.ev_set_mrf_streams_max.argtypes = [vp, i32]
+    lib.ev_set_mrf_streams_max.restype = i32
     lib.ev_workspace_bytes.argtypes = [vp, i32, i32, i32]
     lib.ev_workspace_bytes.restype = u64
     lib.ev_cfm_decode.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp]
@@ -119,6 +121,11 @@ class Engine:
             raise EvLibraryError(f"ev_create failed with code {rc}")
         self.h = h
         self.spk_emb_dim = spk_emb_dim
+
+    def set_mrf_streams_max(self, max_frames: int) -> None:
+        """Largest ``hifigan`` call (B*T mel frames) that runs its three ResBlock1 chains on three streams (0 = never)."""
+        if self.lib.ev_set_mrf_streams_max(self.h, int(max_frames)) != 0:
+            raise EvLibraryError(self.lib.ev_last_error(self.h).decode())
 
     def close(self):
         if getattr(self, "h", None):

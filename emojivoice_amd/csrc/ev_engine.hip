@@ -1595,6 +1595,14 @@ int ev_text_encoder_status(ev_handle* h, void* stream) {
     return 0;
 }
 
+int ev_set_mrf_streams_max(ev_handle* h, int max_frames) {
+    if (!h) return 1;
+    if (max_frames < 0) return fail(h, "ev_set_mrf_streams_max: negative limit");
+    h->mrf_max_frames = max_frames;
+    h->ws_B = -1;   // the plan depends on the limit (scratch of the second and third chain): re-plan on the next call
+    return 0;
+}
+
 size_t ev_workspace_bytes(ev_handle* h, int B, int Tp_cfm, int T_voc) {
     if (!h || B <= 0) return 0;
     return plan_all(h, nullptr, B, Tp_cfm, T_voc, nullptr, nullptr);

@@ -25,6 +25,10 @@ class BatchPipeline:
         self.decode_stream = torch.cuda.Stream(device=dev, priority=pd)
         self.vocoder_stream = torch.cuda.Stream(device=dev, priority=pv)
         self.last_event = None
+        # the vocoder stays on ONE stream here: its small-call fan-out over three streams first drains the caller's stream on
+        # the host (emojivoice.h, ev_hifigan), which would stall this pipeline's enqueue-ahead; the decode stream fills the gaps
+        vocoder._sync_engine()
+        vocoder.engine.set_mrf_streams_max(0)
 
     def submit(self, mu, lengths, spk, z, n_timesteps: int, return_mel: bool = False):
         """mu / z: (B, n_feats, Tp) normalised encoder output and temperature-scaled noise (flow_matching.py:32-50),

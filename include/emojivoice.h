@@ -118,6 +118,11 @@ int ev_text_encoder_status(ev_handle *h, void *stream);
 int ev_align(ev_handle *h, const float *d_wceil, const float *d_mu_x, const int32_t *d_xlen, const int64_t *d_ylen,
              int B, int Tx, int Tp, float *d_mu_y, float *d_attn, void *stream);
 
+/* Largest ev_hifigan call (B*T mel frames) that fans its ResBlock1 chains out over three streams (see ev_hifigan); 0 = never.
+ * Default 16384, or EV_MRF_STREAMS_MAX.  A caller that already overlaps the vocoder with other work on a second stream, and
+ * must not have the host wait inside the call, sets 0 (emojivoice_amd/pipeline.py does). */
+int ev_set_mrf_streams_max(ev_handle *h, int max_frames);
+
 /* HiFi-GAN V1 generator: d_mel (B, 80, T) -> d_wav (B, 256*T), tanh output, no clamp/denoiser.
  * Calls of B*T <= 16384 mel frames (EV_MRF_STREAMS_MAX) first wait for `stream` to drain on the host, then run the three
  * ResBlock1 chains of each level on `stream` and two streams of the handle, joined back into `stream` by events before the
