@@ -304,6 +304,8 @@ def main():
     ap.add_argument("--utterances", type=int, default=128, help="config 5: utterances in the streaming loop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="run CFM and HiFi-GAN of each batch back to back on one stream")
+    ap.add_argument("--pipelines", type=int, default=2, help="batch pipelines in flight (each its own engine pair and two streams); "
+                    "consecutive batches go to them in turn")
     ap.add_argument("--cpu-sample", type=int, default=8)
     ap.add_argument("--plain", action="store_true", help="profiling aid: warm-up + K serial steps and nothing else (no roofline / CPU / PCIe legs), "
                     "so that a rocprofv3 --pmc pass sees exactly (W + K) x launches_per_step conv launches")
@@ -338,17 +340,32 @@ def main():
 
     # consecutive batches are software-pipelined on two HIP streams (emojivoice_amd/pipeline.py): CFM decode of batch i+1
     # on a high-priority stream while HiFi-GAN of batch i runs; --no-pipeline runs the two stages back to back instead
+    # ... and TWO such pipelines are kept in flight (a second engine pair with its own workspace and streams; batches alternate):
+    # with two vocoders and up to two decodes co-scheduled the matrix pipes idle less than with one of each (in-run,
+    # tools/pipeline2_probe.py: 187.9 -> 185.4 ms per batch; a third pipeline adds nothing).  A batch then takes longer from
+    # submission to waveform (see batch_latency_ms for the single-batch latency); `value` is throughput.
     pipe = None if args.no_pipeline else BatchPipeline(model, voc)
+    pipes, extra_models = ([] if pipe is None else [pipe]), []
+    for _ in range(0 if pipe is None else max(0, args.pipelines - 1)):
+        _, _, m2, v2 = build_models(device)
+        extra_models += [m2, v2]
+        pipes.append(BatchPipeline(m2, v2))
+        wv = pipes[-1].submit(mu, lengths, spk, z, n_ode)      # one-time workspace allocation of this engine pair (not a step)
+        pipes[-1].synchronize()
+        del wv
+    turn = [0]
 
     def step():
         """-> (collated waveform of the global batch, this rank's waveform block, this rank's mel)"""
         if pipe is None:
             wav, mel = step_local()
             return (D.all_gather_waveforms(wav, B * world) if world > 1 else wav), wav, mel
-        wav, mel = pipe.submit(mu, lengths, spk, z, n_ode, return_mel=True)
+        p_ = pipes[turn[0] % len(pipes)]
+        turn[0] += 1
+        wav, mel = p_.submit(mu, lengths, spk, z, n_ode, return_mel=True)
         full = wav
         if world > 1:
-            with torch.cuda.stream(pipe.vocoder_stream):
+            with torch.cuda.stream(p_.vocoder_stream):
                 full = D.all_gather_waveforms(wav, B * world)
         return full, wav, mel
 
@@ -482,7 +499,7 @@ def main():
             "config": {"workload": f"config2: batch {B} x {T}-frame (5.99 s) utterances per GPU, {n_ode} Euler steps + HiFi-GAN V1, 22.05 kHz",
                        "global_batch": B * world, "frames": T, "ode_steps": n_ode, "parallelism": f"dp{world}",
                        "collective": "all_gather(waveforms)" if world > 1 else "none",
-                       "batch_pipeline": "off" if pipe is None else "cfm(i+1) || hifigan(i) on two streams"},
+                       "batch_pipeline": "off" if pipe is None else f"cfm(i+1) || hifigan(i) on two streams, {len(pipes)} pipeline(s) in flight"},
             "ranks_seen": ranks_seen, "gathered_shape": gathered_shape,
             "per_gpu_audio_s_per_s": round(per_gpu, 2), "rtf": round(1.0 / per_gpu, 6), "x_realtime_per_gpu": round(per_gpu, 1),
             "serial_ms_per_step": round(serial_ms, 2), "batch_latency_ms": round(batch_latency_ms, 2), "stage_ms": stage_ms,
@@ -493,7 +510,7 @@ def main():
     if world > 1:
         D.barrier()
         torch.distributed.destroy_process_group()
-    close_models(model, voc)
+    close_models(model, voc, *extra_models)
 
 
 if __name__ == "__main__":
