@@ -312,7 +312,7 @@ def main():
     args = ap.parse_args()
 
     from emojivoice_amd import dist as D
-    from emojivoice_amd.pipeline import BatchPipeline
+    from emojivoice_amd.pipeline import PipelineGroup
 
     rank, world, local = D.init_from_env()
     if world != args.gpus:
@@ -344,28 +344,28 @@ def main():
     # with two vocoders and up to two decodes co-scheduled the matrix pipes idle less than with one of each (in-run,
     # tools/pipeline2_probe.py: 187.9 -> 185.4 ms per batch; a third pipeline adds nothing).  A batch then takes longer from
     # submission to waveform (see batch_latency_ms for the single-batch latency); `value` is throughput.
-    pipe = None if args.no_pipeline else BatchPipeline(model, voc)
-    pipes, extra_models = ([] if pipe is None else [pipe]), []
-    for _ in range(0 if pipe is None else max(0, args.pipelines - 1)):
-        _, _, m2, v2 = build_models(device)
-        extra_models += [m2, v2]
-        pipes.append(BatchPipeline(m2, v2))
-        wv = pipes[-1].submit(mu, lengths, spk, z, n_ode)      # one-time workspace allocation of this engine pair (not a step)
-        pipes[-1].synchronize()
-        del wv
-    turn = [0]
+    pipe, extra_models = None, []
+    if not args.no_pipeline:
+        pairs = [(model, voc)]
+        for _ in range(max(0, args.pipelines - 1)):
+            _, _, m2, v2 = build_models(device)
+            extra_models += [m2, v2]
+            pairs.append((m2, v2))
+        pipe = PipelineGroup(pairs)
+        for p_ in pipe.pipes[1:]:                               # one-time workspace allocation of the extra engine pairs (not a step)
+            p_.submit(mu, lengths, spk, z, n_ode)
+            p_.synchronize()
+    pipes = [] if pipe is None else pipe.pipes
 
     def step():
         """-> (collated waveform of the global batch, this rank's waveform block, this rank's mel)"""
         if pipe is None:
             wav, mel = step_local()
             return (D.all_gather_waveforms(wav, B * world) if world > 1 else wav), wav, mel
-        p_ = pipes[turn[0] % len(pipes)]
-        turn[0] += 1
-        wav, mel = p_.submit(mu, lengths, spk, z, n_ode, return_mel=True)
+        wav, mel = pipe.submit(mu, lengths, spk, z, n_ode, return_mel=True)
         full = wav
         if world > 1:
-            with torch.cuda.stream(p_.vocoder_stream):
+            with torch.cuda.stream(pipe.last.vocoder_stream):
                 full = D.all_gather_waveforms(wav, B * world)
         return full, wav, mel
 

@@ -51,3 +51,28 @@ class BatchPipeline:
     def synchronize(self) -> None:
         self.decode_stream.synchronize()
         self.vocoder_stream.synchronize()
+
+
+class PipelineGroup:
+    """Several ``BatchPipeline``s in flight, consecutive batches submitted to them in turn.  Each needs its own (model, vocoder)
+    pair — a native handle owns one workspace and serves one stream user at a time.  Two pipelines keep two vocoders and up to two
+    decodes co-scheduled (bench.py: +1 % throughput at batch 64 over one pipeline; a third adds nothing); results are those of
+    the serial calls, bit for bit."""
+
+    def __init__(self, pairs):
+        self.pipes = [BatchPipeline(m, v) for m, v in pairs]
+        self._turn = 0
+
+    @property
+    def last(self) -> BatchPipeline:
+        """The pipeline the most recent ``submit`` went to (its ``vocoder_stream`` orders the returned tensors)."""
+        return self.pipes[(self._turn - 1) % len(self.pipes)]
+
+    def submit(self, mu, lengths, spk, z, n_timesteps: int, return_mel: bool = False):
+        p = self.pipes[self._turn % len(self.pipes)]
+        self._turn += 1
+        return p.submit(mu, lengths, spk, z, n_timesteps, return_mel=return_mel)
+
+    def synchronize(self) -> None:
+        for p in self.pipes:
+            p.synchronize()

@@ -266,6 +266,35 @@ def test_batch_pipeline_is_bit_identical(model, vocoder):
         assert torch.equal(r, o.cpu())
 
 
+def test_two_pipelines_in_flight_are_bit_identical(model, vocoder, matcha_sd, voc_sd):
+    """PipelineGroup: two batch pipelines (two engine pairs, four streams), batches alternating — what bench.py times."""
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+    from emojivoice_amd.matcha_tts import MatchaTTS
+    from emojivoice_amd.pipeline import PipelineGroup
+
+    model2 = MatchaTTS(matcha_sd, device=model.device)
+    voc2 = Generator(AttrDict(v1)).to(model.device)      # built exactly as the `vocoder` fixture is (weight-norm form, folded)
+    voc2.load_state_dict(W.weight_norm_split(voc_sd))
+    voc2.eval()
+    voc2.remove_weight_norm()
+    g = torch.Generator().manual_seed(34)
+    B, Tp = 2, 44
+    spk = model._sd["spk_emb.weight"][torch.tensor([3, 8]).cuda()]
+    lengths = torch.tensor([44, 30], dtype=torch.int32).cuda()
+    batches = [(torch.randn(B, 80, Tp, generator=g).cuda(), (torch.randn(B, 80, Tp, generator=g) * 0.667).cuda()) for _ in range(5)]
+    ref = []
+    for mu, z in batches:
+        mel = model.engine.cfm_decode(mu, lengths, spk, z, 2, model.mel_std, model.mel_mean)
+        ref.append(vocoder(mel).cpu())
+    group = PipelineGroup([(model, vocoder), (model2, voc2)])
+    outs = [group.submit(mu, lengths, spk, z, 2) for mu, z in batches]
+    group.synchronize()
+    for r, o in zip(ref, outs):
+        assert torch.equal(r, o.cpu())
+    model2.engine.close()
+    voc2.engine.close()
+
+
 def test_device_text_encoder_vs_golden_and_host(golden, model, matcha_sd):
     """ev_text_encoder (HIP kernels through the C ABI) vs the reference-generated golden text-encoder outputs, vs the CPU
     oracle on a ragged batch, and vs the plain-torch host stage."""
