@@ -135,6 +135,12 @@ struct ev_handle {
     // three streams (the caller's + two of the handle's), ordered by events where they join the running sum
     hipStream_t mrf_stream[2] = {nullptr, nullptr};
     hipEvent_t mrf_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // balanced ("stream-K") launches, see SkCtl in ev_kernels.h: control words + flags (zeroed once) and the partial-tile slots
+    int ncu = 0;                    // compute units of the device
+    unsigned* sk_ctrl = nullptr;    // [0] epoch [1] arrivals [2] timed-out waits | flags from word 16 on
+    float* sk_part = nullptr;
+    bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
+    int sk_spin = 20000;            // EV_SK_SPIN=<polls> before an owner recomputes a contributor's share itself (~1.5 us per poll)
     int mrf_max_frames = 16384;     // EV_MRF_STREAMS_MAX=<B*T mel frames>: calls up to this size use the three streams (0 = never).  Six more scratch
                                     // tensors per level; at batch 64 x 516 frames (21 GB) the two-stage pipeline of bench.py already fills the gaps:
                                     // -1.4 % on the vocoder alone, +0.6 % on the pipelined step
@@ -728,6 +734,18 @@ int launch_ln(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const fl
     return 0;
 }
 
+constexpr int EV_SK_MAXWG = 1024;          // persistent workgroups of a balanced launch (<= 4 per CU on 256 CUs)
+constexpr int EV_SK_PART_FLOATS = 16384;   // largest partial accumulator tile handed over (64 KB: a 64 x 192 conv tile is 48 KB)
+// Hand-off area of the balanced launches: allocated once per handle (never inside a stream capture: ev_load_estimator calls this)
+int ensure_sk(ev_handle* h) {
+    if (h->sk_ctrl) return 0;
+    const size_t words = 16 + EV_SK_MAXWG;
+    HIPCHK(h, hipMalloc((void**)&h->sk_ctrl, words * sizeof(unsigned)));
+    HIPCHK(h, hipMemset(h->sk_ctrl, 0, words * sizeof(unsigned)));
+    HIPCHK(h, hipMalloc((void**)&h->sk_part, (size_t)EV_SK_MAXWG * 2 * EV_SK_PART_FLOATS * sizeof(float)));   // (freed by ev_destroy)
+    return 0;
+}
+
 // LayerNorm + feed-forward (mode 0) or LayerNorm + QKV projection (mode 1) of one transformer block in one launch
 // (ln_mlp_kernel).  Counted as ONE conv launch of the dominant-kernel family by the profiling hooks (its FLOPs are those of
 // the linears it contains).
@@ -754,8 +772,22 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
         return fail(h, "launch_mlp: second linear must be %d -> 256 with bias", L1.Cout);
     if ((double)g.nrows * std::max(ldy, 256) * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
     if (g.S < 4 && g.nrows > 1) return fail(h, "launch_mlp: utterance stride %d < 4 rows is not supported by the lean row walk", g.S);
-    const int ntiles = (g.nrows + 31) / 32;
-    const size_t smem = (size_t)(32 * 260 + 4 * 32 * 36) * sizeof(float);
+    const int ntiles = (g.nrows + 31) / 32, nchunk = L1.Mpad / 128;
+    size_t smem = (size_t)(32 * 260 + 4 * 32 * 36 + 4) * sizeof(float);
+    // Balanced persistent grid (SkCtl): three workgroups per CU — the LDS request is padded so that exactly three fit, i.e. every
+    // CU holds the same number of them — each taking an equal share of the (tile, 128-wide chunk) units.  From one tile per CU up;
+    // below that the launch is a latency chain per workgroup and keeps one tile each.
+    int grid = ntiles;
+    mp.ntiles = ntiles;
+    mp.sk.q = nchunk; mp.sk.r = 0; mp.sk.spin_limit = h->sk_spin;
+    if (h->sk_balance && h->ncu > 0 && ntiles >= h->ncu && 3 * h->ncu <= EV_SK_MAXWG && (long)ntiles * nchunk >= 3L * h->ncu) {
+        if (ensure_sk(h)) return 1;
+        grid = 3 * h->ncu;
+        const long U = (long)ntiles * nchunk;
+        mp.sk.q = (int)(U / grid); mp.sk.r = (int)(U % grid);
+        mp.sk.ctrl = h->sk_ctrl; mp.sk.flags = h->sk_ctrl + 16; mp.sk.part = h->sk_part; mp.sk.part_floats = EV_SK_PART_FLOATS;
+        smem = std::max(smem, (size_t)((160 * 1024 / 3) & ~255));
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         if (h->ev_used + 2 > h->ev_pool.size()) {
@@ -764,8 +796,8 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
         e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
-    if (mode == 0) hipLaunchKernelGGL(ln_mlp_kernel<0>, dim3(ntiles), dim3(256), smem, h->stream, mp);
-    else hipLaunchKernelGGL(ln_mlp_kernel<1>, dim3(ntiles), dim3(256), smem, h->stream, mp);
+    if (mode == 0) hipLaunchKernelGGL(ln_mlp_kernel<0>, dim3(grid), dim3(256), smem, h->stream, mp);
+    else hipLaunchKernelGGL(ln_mlp_kernel<1>, dim3(grid), dim3(256), smem, h->stream, mp);
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
         HIPCHK(h, hipEventRecord(e1, h->stream));
@@ -1296,6 +1328,9 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     { const char* fp = getenv("EV_FUSE_MLP"); if (fp && *fp == '0') h->fuse_mlp = false; }
     { const char* fp = getenv("EV_FUSE_MLP_MIN"); if (fp && *fp) h->fuse_mlp_min_tiles = atoi(fp); }
     { const char* fp = getenv("EV_MRF_STREAMS_MAX"); if (fp && *fp) h->mrf_max_frames = atoi(fp); }
+    { const char* fp = getenv("EV_NO_SK_BALANCE"); if (fp && *fp && *fp != '0') h->sk_balance = false; }
+    { const char* fp = getenv("EV_SK_SPIN"); if (fp && *fp) h->sk_spin = atoi(fp); }
+    if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) h->ncu = 0;
     // the shipped decoder configuration (configs/model/decoder/default.yaml: 2 heads x 64) is the only one the workspace
     // plan and the transformer launch sequence are laid out for
     if (dims->n_feats != 80 || dims->channels != 256 || dims->head_dim != 64 || dims->heads != 2) {
@@ -1312,6 +1347,8 @@ void ev_destroy(ev_handle* h) {
     hipDeviceSynchronize();
     for (void* p : h->owned) hipFree(p);
     if (h->ws) hipFree(h->ws);
+    if (h->sk_ctrl) hipFree(h->sk_ctrl);
+    if (h->sk_part) hipFree(h->sk_part);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
     if (h->enc_ws.p) hipFree(h->enc_ws.p);
     if (h->dn_ws.p) hipFree(h->dn_ws.p);
@@ -1342,6 +1379,7 @@ int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* in
     HIPCHK(h, hipSetDevice(h->device));
     TensorMap m;
     if (build_map(h, blob, index, n, m)) return 1;
+    if (ensure_sk(h)) return 1;
     EstimatorW& w = h->est;
     w.loaded = false;
 #define T_(k) find(h, m, k)

@@ -1492,6 +1492,74 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const LNParams p) {
 // HBM.  Accumulation order over k is the unfused kernels' (bias first, k ascending), so results are bit-identical to them.
 // Weights stream from L2 in MFMA-fragment order as in conv_gemm_kernel, four k-groups ahead.
 // ---------------------------------------------------------------------------
+// ---------------------------------------------------------------------------
+// Balanced work assignment inside ONE launch ("stream-K").  The U-Net launches of a batch-64 decode are about one round of
+// workgroups, so a launch lasts as long as its busiest CU: 520 row tiles of a feed-forward on 256 CUs leave eight CUs with three
+// tiles while the others hold two (measured with tools/shape_profile.py: 62 utterances — 504 tiles — decode 14 % faster than
+// 64 for 3 % less work).  Here a launch is G persistent workgroups (G = CUs x workgroups that fit a CU), the work is cut into
+// UNITS finer than a tile (a feed-forward row tile = 8 hidden-width chunks), and workgroup g takes the contiguous unit range
+// [start(g), start(g + 1)), start(x) = x * q + min(x, r) with q = U / G, r = U % G.  A tile whose units straddle two (or three)
+// workgroups is finished by the OWNER — the workgroup holding its first unit, which reaches it LAST in its own range — the others
+// reach their share of it FIRST and publish an un-biased partial accumulator tile, which the owner adds in ascending workgroup
+// order (deterministic).  Hand-off = MI355X guide, Guideline 16 R1: write-through (sc1) payload stores, every storing wave drains
+// vmcnt, workgroup barrier, ONE lane stores the flag with an agent-scope atomic; the consumer polls that word relaxed, ONE agent
+// acquire, barrier, then sc1 loads.  Flags carry a launch tag (device-side epoch word + 1, bumped by the last workgroup to
+// arrive at the end of the launch), so nothing has to be zeroed per launch and a replayed hipGraph stays correct.
+// No protocol step depends on dispatch order or residency: a publisher never waits before it publishes, and an owner whose wait
+// runs out (a contributor that is not resident yet) recomputes the missing share itself AS A SEPARATE partial sum, i.e. with
+// the bits the contributor would have delivered — slower, never different, never a hang.
+// ---------------------------------------------------------------------------
+struct SkCtl {
+    unsigned* ctrl;      // [0] epoch, [1] arrivals of the running launch, [2] waits that ran out (diagnostic); null = no hand-offs
+    unsigned* flags;     // one word per workgroup: tag of the launch whose partial is in that workgroup's slot
+    float* part;         // per workgroup: two tiles of `part_floats` (published partial | private spill of the fallback path)
+    int part_floats;
+    int q, r;            // units per workgroup: start(x) = x * q + min(x, r)
+    int spin_limit;      // polls before an owner gives up waiting
+};
+typedef __attribute__((address_space(1))) unsigned ev_gu32;
+__device__ __forceinline__ int sk_start(const SkCtl& c, int x) { return x * c.q + (x < c.r ? x : c.r); }
+__device__ __forceinline__ unsigned sk_tag(const SkCtl& c) {
+    return c.ctrl ? (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((ev_gu32*)c.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u : 0u;
+}
+__device__ __forceinline__ f32x4 ev_bload4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, 0, 16));    // aux 16 = sc1: served by L2, never a stale L1 line
+}
+__device__ __forceinline__ void ev_bstore4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff_bytes, 0, 16);       // write-through
+}
+// after every wave's payload stores: drain, meet, ONE lane raises the flag
+__device__ __forceinline__ void sk_publish(const SkCtl& c, int g, unsigned tag, int tid) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid == 0) __hip_atomic_store((ev_gu32*)(c.flags + g), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// true when workgroup gi's partial of this launch is readable by every wave of the caller (all threads must call; `word` = one LDS int)
+__device__ __forceinline__ bool sk_wait(const SkCtl& c, int gi, unsigned tag, int tid, int* word) {
+    if (tid == 0) {
+        int ok = 0;
+        for (int spins = 0; spins < c.spin_limit; ++spins) {
+            if (__hip_atomic_load((ev_gu32*)(c.flags + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!ok) atomicAdd(c.ctrl + 2, 1u);
+        *word = ok;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool ok = *word != 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (the word may be rewritten by the next wait)
+    return ok;
+}
+// end of the launch: the last workgroup to arrive advances the epoch (next launch: tag + 1) and re-arms the counter
+__device__ __forceinline__ void sk_arrive(const SkCtl& c, unsigned tag, int tid) {
+    if (!c.ctrl || tid != 0) return;
+    const unsigned old = __hip_atomic_fetch_add((ev_gu32*)(c.ctrl + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == gridDim.x) {
+        __hip_atomic_store((ev_gu32*)(c.ctrl + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((ev_gu32*)c.ctrl, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 struct MlpParams {
     ConvParams ep;                 // epilogue view of the LAST linear: Y / ldy / Cout / bias, R / ldr, rowmask / mask2, nrows / S / P / T
     const float* X; int ldx;       // (rows, 256) input of the LayerNorm
@@ -1499,8 +1567,12 @@ struct MlpParams {
     const float* W1; const float* b1; int M1;        // fragment order [M1/32][256/8][64][4]; M1 a multiple of 128
     const float* alpha; const float* binv;           // SnakeBeta vectors over the hidden width (MODE 0)
     const float* W2;                                 // fragment order [256/32][M1/8][64][4] (MODE 0)
+    int ntiles;                    // 32-row tiles of the launch; the grid is either ntiles workgroups (one tile each: sk.q = M1 / 128,
+    SkCtl sk;                      // sk.r = 0, no hand-offs) or the balanced persistent grid described at SkCtl
 };
 
+// unit = (32-row tile, 128-wide chunk of the hidden [MODE 1: output] width); a workgroup walks its unit range tile segment by tile
+// segment: stage + LayerNorm the tile's rows once per segment, then the chunks [c0, c1) of it.
 template <int MODE>   // (LDS admits three workgroups per CU: keep the register allocation at three waves per SIMD)
 __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
     constexpr int NT = 32, C = 256, XLD = C + 4, HC = 128, HLD = HC + 4;
@@ -1508,22 +1580,18 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Xs = smem;                                  // [NT][XLD] normalised input rows (B operand of phase 1)
     float* Hs = smem + NT * XLD;                       // [NT][HLD] hidden chunk (B operand of phase 2); MODE 1: epilogue slabs
+    int* skw = (int*)(smem + NT * XLD + 4 * 32 * 36);   // one word for sk_wait (plain LDS accesses: the asm barriers around it order them)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.x * NT;
-    {   // tiles that contain no storable row (pure padding) do nothing
-        int t_first = (n0 % p.S) - p.P;
-        int dist;
-        if (t_first >= 0 && t_first < p.T) dist = 0;
-        else if (t_first < 0) dist = -t_first;
-        else dist = p.S - (n0 % p.S) + p.P;
-        if (dist >= NT || n0 + dist >= p.nrows) return;
-    }
     const __amdgpu_buffer_rsrc_t rX = ev_rsrc(mp.X), rW1 = ev_rsrc(mp.W1), rW2 = ev_rsrc(MODE == 0 ? mp.W2 : mp.W1);
     const unsigned wlane = (unsigned)lane * 16u;
     const int nchunk = mp.M1 / HC;
     const int KG2 = mp.M1 / 8;                          // k-groups per row tile of W2
+    const int g = blockIdx.x;
+    const unsigned tag = MODE == 0 ? sk_tag(mp.sk) : 0u;
+    int u = sk_start(mp.sk, g);
+    const int ue = sk_start(mp.sk, g + 1);
     // ONE set of eight fragment registers serves both phases: phase 1 (one 32-row tile of W1, 4 MFMAs per fragment) runs eight
     // k-groups ahead, phase 2 (two row tiles of W2, 8 MFMAs per fragment pair) four — 32 MFMAs of cover either way.  In the last
     // eight (four) k-groups of a phase every register, once consumed, is refilled with the first fragments of the NEXT phase, so
@@ -1531,165 +1599,256 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
     f32x4 F0, F1, F2, F3, F4, F5, F6, F7;
     auto ldP = [&](int ht, int kg) { return ev_bload4(rW1, wlane, (unsigned)(ht * (C / 8) + kg) * 1024u); };
     auto ldQ = [&](int hc, int kg, int a) { return ev_bload4(rW2, wlane, (unsigned)((wave * 2 + a) * KG2 + hc * (HC / 8) + kg) * 1024u); };
-    F0 = ldP(wave, 0); F1 = ldP(wave, 1); F2 = ldP(wave, 2); F3 = ldP(wave, 3);
-    F4 = ldP(wave, 4); F5 = ldP(wave, 5); F6 = ldP(wave, 6); F7 = ldP(wave, 7);
-    {   // ---- stage the 32 x 256 input rows: all loads first (one latency episode)
-        f32x4 xv[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int i = q * 256 + tid, r = i >> 6, c4 = (i & 63) * 4, gr = n0 + r;
-            xv[q] = ev_bload4(rX, ((unsigned)(gr < p.nrows ? gr : 0) * mp.ldx + c4) * 4u, 0);   // (beyond the tensor: pad row 0)
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int i = q * 256 + tid, r = i >> 6, c4 = (i & 63) * 4;
-            *(f32x4*)(Xs + r * XLD + c4) = xv[q];
-        }
-    }
-    ev_lds_barrier();
-    {   // ---- LayerNorm in place: wave w owns rows 8w .. 8w+7, one row = 4 channels per lane
-        const f32x4 g = *(const f32x4*)(mp.ln_g + lane * 4), be = *(const f32x4*)(mp.ln_b + lane * 4);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            float* row = Xs + (wave * 8 + r) * XLD + lane * 4;
-            *(f32x4*)row = ev_ln256_row(*(const f32x4*)row, g, be, mp.ln_eps);
-        }
-    }
-    ev_lds_barrier();
-
-    f32x16 acc2[2][1];                                 // MODE 0: this wave's 64 output channels x 32 frames, alive across all chunks
-    if constexpr (MODE == 0) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 bq = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bq = *(const f32x4*)(p.bias + wave * 64 + a * 32 + 8 * g + 4 * lh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc2[a][0][4 * g + e] = bq[e];
-            }
-        }
-    }
-    const float* xrow = Xs + li * XLD + 4 * lh;
-    const float* hrow = Hs + li * HLD + 4 * lh;
-
     // Per-channel vectors of the hidden width (bias, SnakeBeta alpha / 1/beta) are requested one phase before their use, as
     // part of the same counted load stream: fetched at the point of use they put one exposed L2 round trip (and a vmcnt(0) that
     // drained the fragment ring) into every chunk — twice.  mp.b1 always points at readable memory (zeros when the layer has no bias).
     const __amdgpu_buffer_rsrc_t rB1 = ev_rsrc(mp.b1), rSa = ev_rsrc(MODE == 0 ? mp.alpha : mp.b1), rSb = ev_rsrc(MODE == 0 ? mp.binv : mp.b1);
     const unsigned coff = (unsigned)(4 * lh) * 4u;     // C/D register 4g+e of a 32-channel tile is channel 8g + 4*half + e
-    f32x4 bq[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB1, coff + (unsigned)(wave * 32 + 8 * g) * 4u, 0);
+    const float* xrow = Xs + li * XLD + 4 * lh;
+    const float* hrow = Hs + li * HLD + 4 * lh;
+    // this workgroup's slot of the hand-off area: [published partial | private spill]; element (wave, a, q) of a tile = 64 lanes x 16 B
+    const __amdgpu_buffer_rsrc_t rPart = ev_rsrc(mp.sk.part);
+    const unsigned pslot = (unsigned)mp.sk.part_floats * 8u;            // bytes per workgroup (two tiles)
+    const unsigned pelem = (unsigned)(wave * 8) * 1024u + wlane;
 
-    for (int hc = 0; hc < nchunk; ++hc) {
-        const int ht = hc * 4 + wave;                  // this wave's 32 hidden (MODE 1: output) channels of the chunk
-        const int htn = hc + 1 < nchunk ? ht + 4 : wave;   // next chunk's tile (after the last chunk: a harmless re-read)
-        // ================= phase 1: acc1 = W1[ht] . LN(x) + b1, K = 256 = 32 k-groups =================
-        f32x16 acc1;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc1[4 * g + e] = bq[g][e];
-        f32x4 sa[4], sb[4];
-        if constexpr (MODE == 0) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                sa[g] = ev_bload4(rSa, coff + (unsigned)(ht * 32 + 8 * g) * 4u, 0);
-                sb[g] = ev_bload4(rSb, coff + (unsigned)(ht * 32 + 8 * g) * 4u, 0);
-            }
-        } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB1, coff + (unsigned)(htn * 32 + 8 * g) * 4u, 0);   // next chunk's bias
+    while (u < ue) {
+        const int t = u / nchunk, c0 = u - t * nchunk;
+        const int c1 = (ue - u < nchunk - c0) ? c0 + (ue - u) : nchunk;
+        u += c1 - c0;
+        const int n0 = t * NT;
+        {   // tiles that contain no storable row (pure padding) do nothing — owner and contributors agree, the test only reads t
+            int t_first = (n0 % p.S) - p.P;
+            int dist;
+            if (t_first >= 0 && t_first < p.T) dist = 0;
+            else if (t_first < 0) dist = -t_first;
+            else dist = p.S - (n0 % p.S) + p.P;
+            if (dist >= NT || n0 + dist >= p.nrows) continue;
         }
-        {
-            f32x4 B0 = *(const f32x4*)(xrow), B1;
-            auto mma1 = [&](const f32x4& a, const f32x4& b) {
+        F0 = ldP(c0 * 4 + wave, 0); F1 = ldP(c0 * 4 + wave, 1); F2 = ldP(c0 * 4 + wave, 2); F3 = ldP(c0 * 4 + wave, 3);
+        F4 = ldP(c0 * 4 + wave, 4); F5 = ldP(c0 * 4 + wave, 5); F6 = ldP(c0 * 4 + wave, 6); F7 = ldP(c0 * 4 + wave, 7);
+        ev_lds_barrier();                              // the previous segment's epilogue is done with its LDS slabs
+        {   // ---- stage the 32 x 256 input rows: all loads first (one latency episode)
+            f32x4 xv[8];
 #pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc1, 0, 0, 0);
-            };
-            // one k-group: B fragment of the next k-group, 4 MFMAs, refill of the consumed register
-#define EV_P1_STEP(F, BC, BN_, I, REFILL)                                                        \
-            BN_ = *(const f32x4*)(xrow + ((kb + (I) + 1) & 31) * 8);                              \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-            mma1(F, BC);                                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-            F = REFILL;
-#pragma unroll 1
-            for (int kb = 0; kb < 24; kb += 8) {
-                EV_P1_STEP(F0, B0, B1, 0, ldP(ht, kb + 8))  EV_P1_STEP(F1, B1, B0, 1, ldP(ht, kb + 9))
-                EV_P1_STEP(F2, B0, B1, 2, ldP(ht, kb + 10)) EV_P1_STEP(F3, B1, B0, 3, ldP(ht, kb + 11))
-                EV_P1_STEP(F4, B0, B1, 4, ldP(ht, kb + 12)) EV_P1_STEP(F5, B1, B0, 5, ldP(ht, kb + 13))
-                EV_P1_STEP(F6, B0, B1, 6, ldP(ht, kb + 14)) EV_P1_STEP(F7, B1, B0, 7, ldP(ht, kb + 15))
+            for (int q = 0; q < 8; ++q) {
+                const int i = q * 256 + tid, r = i >> 6, c4 = (i & 63) * 4, gr = n0 + r;
+                xv[q] = ev_bload4(rX, ((unsigned)(gr < p.nrows ? gr : 0) * mp.ldx + c4) * 4u, 0);   // (beyond the tensor: pad row 0)
             }
-            {   // last eight k-groups: the registers go over to the next phase
-                constexpr int kb = 24;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int i = q * 256 + tid, r = i >> 6, c4 = (i & 63) * 4;
+                *(f32x4*)(Xs + r * XLD + c4) = xv[q];
+            }
+        }
+        ev_lds_barrier();
+        {   // ---- LayerNorm in place: wave w owns rows 8w .. 8w+7, one row = 4 channels per lane
+            const f32x4 gm = *(const f32x4*)(mp.ln_g + lane * 4), be = *(const f32x4*)(mp.ln_b + lane * 4);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float* row = Xs + (wave * 8 + r) * XLD + lane * 4;
+                *(f32x4*)row = ev_ln256_row(*(const f32x4*)row, gm, be, mp.ln_eps);
+            }
+        }
+        ev_lds_barrier();
+
+        // ---- passes over chunk ranges of this tile: [c0, c1) first; an owner whose wait for a contributor ran out adds one pass
+        // over that contributor's range (fresh accumulators: the contributor's bits)
+        int cA = c0, cB = c1;
+        bool spilled = false;
+        int gi = g + 1;                                // next contributor of this tile (owner only)
+        const int tile_end = (t + 1) * nchunk;
+        for (;;) {
+            f32x16 acc2[2][1];                         // MODE 0: this wave's 64 output channels x 32 frames, alive across all chunks of the pass
+            if constexpr (MODE == 0) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+                        if (p.bias && cA == 0) bq = *(const f32x4*)(p.bias + wave * 64 + a * 32 + 8 * q + 4 * lh);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc2[a][0][4 * q + e] = bq[e];
+                    }
+                }
+            }
+            f32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = ev_bload4(rB1, coff + (unsigned)((cA * 4 + wave) * 32 + 8 * q) * 4u, 0);
+
+            for (int hc = cA; hc < cB; ++hc) {
+                const int ht = hc * 4 + wave;                  // this wave's 32 hidden (MODE 1: output) channels of the chunk
+                const int htn = hc + 1 < cB ? ht + 4 : cA * 4 + wave;   // next chunk's tile (after the last chunk: a harmless re-read)
+                // ================= phase 1: acc1 = W1[ht] . LN(x) + b1, K = 256 = 32 k-groups =================
+                f32x16 acc1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc1[4 * q + e] = bq[q][e];
+                f32x4 sa[4], sb[4];
                 if constexpr (MODE == 0) {
-                    EV_P1_STEP(F0, B0, B1, 0, ldQ(hc, 0, 0)) EV_P1_STEP(F1, B1, B0, 1, ldQ(hc, 0, 1))
-                    EV_P1_STEP(F2, B0, B1, 2, ldQ(hc, 1, 0)) EV_P1_STEP(F3, B1, B0, 3, ldQ(hc, 1, 1))
-                    EV_P1_STEP(F4, B0, B1, 4, ldQ(hc, 2, 0)) EV_P1_STEP(F5, B1, B0, 5, ldQ(hc, 2, 1))
-                    EV_P1_STEP(F6, B0, B1, 6, ldQ(hc, 3, 0)) EV_P1_STEP(F7, B1, B0, 7, ldQ(hc, 3, 1))
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sa[q] = ev_bload4(rSa, coff + (unsigned)(ht * 32 + 8 * q) * 4u, 0);
+                        sb[q] = ev_bload4(rSb, coff + (unsigned)(ht * 32 + 8 * q) * 4u, 0);
+                    }
                 } else {
-                    EV_P1_STEP(F0, B0, B1, 0, ldP(htn, 0)) EV_P1_STEP(F1, B1, B0, 1, ldP(htn, 1))
-                    EV_P1_STEP(F2, B0, B1, 2, ldP(htn, 2)) EV_P1_STEP(F3, B1, B0, 3, ldP(htn, 3))
-                    EV_P1_STEP(F4, B0, B1, 4, ldP(htn, 4)) EV_P1_STEP(F5, B1, B0, 5, ldP(htn, 5))
-                    EV_P1_STEP(F6, B0, B1, 6, ldP(htn, 6)) EV_P1_STEP(F7, B1, B0, 7, ldP(htn, 7))
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[q] = ev_bload4(rB1, coff + (unsigned)(htn * 32 + 8 * q) * 4u, 0);   // next chunk's bias
                 }
-            }
-#undef EV_P1_STEP
-        }
-        if constexpr (MODE == 1) {
-            // ---- projection only: store this wave's 32 channels x 32 frames (per-wave slab in the Hs region)
-            f32x16 accs[1][1];
-            accs[0][0] = acc1;
-            conv_epilogue_lean<1, 1, 1>(p, accs, Hs + wave * (32 * 36), ht * 32, n0, lane);
-            continue;
-        } else {
-            // ---- h = SnakeBeta(acc1) into Hs[frame][hidden channel]; C/D register 4g+e is channel 8g + 4*half + e
-            f32x4 hv[4];
+                {
+                    f32x4 B0 = *(const f32x4*)(xrow), B1;
+                    auto mma1 = [&](const f32x4& a, const f32x4& b) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const float v = acc1[4 * g + e]; hv[g][e] = fmaf(sb[g][e], ev_sin2(v * sa[g][e]), v); }
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) bq[g] = ev_bload4(rB1, coff + (unsigned)(htn * 32 + 8 * g) * 4u, 0);   // next chunk's bias, under phase 2
-            ev_lds_barrier();        // every wave is done reading the previous chunk's Hs (its phase 2)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) *(f32x4*)(Hs + li * HLD + wave * 32 + 8 * g + 4 * lh) = hv[g];
-            ev_lds_barrier();
-            // ================= phase 2: acc2 += W2[64 channels of this wave][chunk] . h, K = 128 = 16 k-groups =================
-            f32x4 B0 = *(const f32x4*)(hrow), B1;
-            auto mma2 = [&](const f32x4& a0, const f32x4& a1, const f32x4& b) {
-#pragma unroll
-                for (int s4 = 0; s4 < 4; ++s4) {
-                    acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], b[s4], acc2[0][0], 0, 0, 0);
-                    acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], b[s4], acc2[1][0], 0, 0, 0);
-                }
-            };
-#define EV_P2_STEP(FA, FB, BC, BN_, I, RA, RB)                                                   \
-            BN_ = *(const f32x4*)(hrow + ((kb + (I) + 1) & 15) * 8);                              \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-            mma2(FA, FB, BC);                                                                    \
-            __builtin_amdgcn_sched_barrier(0);                                                   \
-            FA = RA; FB = RB;
+                        for (int s4 = 0; s4 < 4; ++s4) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s4], b[s4], acc1, 0, 0, 0);
+                    };
+                    // one k-group: B fragment of the next k-group, 4 MFMAs, refill of the consumed register
+#define EV_P1_STEP(F, BC, BN_, I, REFILL)                                                        \
+                    BN_ = *(const f32x4*)(xrow + ((kb + (I) + 1) & 31) * 8);                      \
+                    __builtin_amdgcn_sched_barrier(0);                                           \
+                    mma1(F, BC);                                                                 \
+                    __builtin_amdgcn_sched_barrier(0);                                           \
+                    F = REFILL;
 #pragma unroll 1
-            for (int kb = 0; kb < 12; kb += 4) {
-                EV_P2_STEP(F0, F1, B0, B1, 0, ldQ(hc, kb + 4, 0), ldQ(hc, kb + 4, 1)) EV_P2_STEP(F2, F3, B1, B0, 1, ldQ(hc, kb + 5, 0), ldQ(hc, kb + 5, 1))
-                EV_P2_STEP(F4, F5, B0, B1, 2, ldQ(hc, kb + 6, 0), ldQ(hc, kb + 6, 1)) EV_P2_STEP(F6, F7, B1, B0, 3, ldQ(hc, kb + 7, 0), ldQ(hc, kb + 7, 1))
-            }
-            {   // last four k-groups: the registers go back to phase 1 of the next chunk
-                constexpr int kb = 12;
-                EV_P2_STEP(F0, F1, B0, B1, 0, ldP(htn, 0), ldP(htn, 1)) EV_P2_STEP(F2, F3, B1, B0, 1, ldP(htn, 2), ldP(htn, 3))
-                EV_P2_STEP(F4, F5, B0, B1, 2, ldP(htn, 4), ldP(htn, 5)) EV_P2_STEP(F6, F7, B1, B0, 3, ldP(htn, 6), ldP(htn, 7))
-            }
+                    for (int kb = 0; kb < 24; kb += 8) {
+                        EV_P1_STEP(F0, B0, B1, 0, ldP(ht, kb + 8))  EV_P1_STEP(F1, B1, B0, 1, ldP(ht, kb + 9))
+                        EV_P1_STEP(F2, B0, B1, 2, ldP(ht, kb + 10)) EV_P1_STEP(F3, B1, B0, 3, ldP(ht, kb + 11))
+                        EV_P1_STEP(F4, B0, B1, 4, ldP(ht, kb + 12)) EV_P1_STEP(F5, B1, B0, 5, ldP(ht, kb + 13))
+                        EV_P1_STEP(F6, B0, B1, 6, ldP(ht, kb + 14)) EV_P1_STEP(F7, B1, B0, 7, ldP(ht, kb + 15))
+                    }
+                    {   // last eight k-groups: the registers go over to the next phase
+                        constexpr int kb = 24;
+                        if constexpr (MODE == 0) {
+                            EV_P1_STEP(F0, B0, B1, 0, ldQ(hc, 0, 0)) EV_P1_STEP(F1, B1, B0, 1, ldQ(hc, 0, 1))
+                            EV_P1_STEP(F2, B0, B1, 2, ldQ(hc, 1, 0)) EV_P1_STEP(F3, B1, B0, 3, ldQ(hc, 1, 1))
+                            EV_P1_STEP(F4, B0, B1, 4, ldQ(hc, 2, 0)) EV_P1_STEP(F5, B1, B0, 5, ldQ(hc, 2, 1))
+                            EV_P1_STEP(F6, B0, B1, 6, ldQ(hc, 3, 0)) EV_P1_STEP(F7, B1, B0, 7, ldQ(hc, 3, 1))
+                        } else {
+                            EV_P1_STEP(F0, B0, B1, 0, ldP(htn, 0)) EV_P1_STEP(F1, B1, B0, 1, ldP(htn, 1))
+                            EV_P1_STEP(F2, B0, B1, 2, ldP(htn, 2)) EV_P1_STEP(F3, B1, B0, 3, ldP(htn, 3))
+                            EV_P1_STEP(F4, B0, B1, 4, ldP(htn, 4)) EV_P1_STEP(F5, B1, B0, 5, ldP(htn, 5))
+                            EV_P1_STEP(F6, B0, B1, 6, ldP(htn, 6)) EV_P1_STEP(F7, B1, B0, 7, ldP(htn, 7))
+                        }
+                    }
+#undef EV_P1_STEP
+                }
+                if constexpr (MODE == 1) {
+                    // ---- projection only: store this wave's 32 channels x 32 frames (per-wave slab in the Hs region)
+                    f32x16 accs[1][1];
+                    accs[0][0] = acc1;
+                    conv_epilogue_lean<1, 1, 1>(p, accs, Hs + wave * (32 * 36), ht * 32, n0, lane);
+                    continue;
+                } else {
+                    // ---- h = SnakeBeta(acc1) into Hs[frame][hidden channel]; C/D register 4g+e is channel 8g + 4*half + e
+                    f32x4 hv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float v = acc1[4 * q + e]; hv[q][e] = fmaf(sb[q][e], ev_sin2(v * sa[q][e]), v); }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[q] = ev_bload4(rB1, coff + (unsigned)(htn * 32 + 8 * q) * 4u, 0);   // next chunk's bias, under phase 2
+                    ev_lds_barrier();        // every wave is done reading the previous chunk's Hs (its phase 2)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *(f32x4*)(Hs + li * HLD + wave * 32 + 8 * q + 4 * lh) = hv[q];
+                    ev_lds_barrier();
+                    // ================= phase 2: acc2 += W2[64 channels of this wave][chunk] . h, K = 128 = 16 k-groups =================
+                    f32x4 B0 = *(const f32x4*)(hrow), B1;
+                    auto mma2 = [&](const f32x4& a0, const f32x4& a1, const f32x4& b) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; ++s4) {
+                            acc2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s4], b[s4], acc2[0][0], 0, 0, 0);
+                            acc2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s4], b[s4], acc2[1][0], 0, 0, 0);
+                        }
+                    };
+#define EV_P2_STEP(FA, FB, BC, BN_, I, RA, RB)                                                   \
+                    BN_ = *(const f32x4*)(hrow + ((kb + (I) + 1) & 15) * 8);                      \
+                    __builtin_amdgcn_sched_barrier(0);                                           \
+                    mma2(FA, FB, BC);                                                            \
+                    __builtin_amdgcn_sched_barrier(0);                                           \
+                    FA = RA; FB = RB;
+#pragma unroll 1
+                    for (int kb = 0; kb < 12; kb += 4) {
+                        EV_P2_STEP(F0, F1, B0, B1, 0, ldQ(hc, kb + 4, 0), ldQ(hc, kb + 4, 1)) EV_P2_STEP(F2, F3, B1, B0, 1, ldQ(hc, kb + 5, 0), ldQ(hc, kb + 5, 1))
+                        EV_P2_STEP(F4, F5, B0, B1, 2, ldQ(hc, kb + 6, 0), ldQ(hc, kb + 6, 1)) EV_P2_STEP(F6, F7, B1, B0, 3, ldQ(hc, kb + 7, 0), ldQ(hc, kb + 7, 1))
+                    }
+                    {   // last four k-groups: the registers go back to phase 1 of the next chunk
+                        constexpr int kb = 12;
+                        EV_P2_STEP(F0, F1, B0, B1, 0, ldP(htn, 0), ldP(htn, 1)) EV_P2_STEP(F2, F3, B1, B0, 1, ldP(htn, 2), ldP(htn, 3))
+                        EV_P2_STEP(F4, F5, B0, B1, 2, ldP(htn, 4), ldP(htn, 5)) EV_P2_STEP(F6, F7, B1, B0, 3, ldP(htn, 6), ldP(htn, 7))
+                    }
 #undef EV_P2_STEP
+                }
+            }
+            if constexpr (MODE == 1) break;
+            else {
+                if (spilled) {                         // fallback pass done: running sum (spilled) + this contributor's share
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = ev_bload4_sc1(rPart, (unsigned)g * pslot + pslot / 2 + pelem + (unsigned)(a * 4 + q) * 1024u);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc2[a][0][4 * q + e] += v[e];
+                        }
+                    spilled = false;
+                }
+                if (c0 != 0) {                         // not the owner: publish the partial tile (no bias) and move on
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4 v = {acc2[a][0][4 * q], acc2[a][0][4 * q + 1], acc2[a][0][4 * q + 2], acc2[a][0][4 * q + 3]};
+                            ev_bstore4_sc1(rPart, (unsigned)g * pslot + pelem + (unsigned)(a * 4 + q) * 1024u, v);
+                        }
+                    sk_publish(mp.sk, g, tag, tid);
+                    break;
+                }
+                // owner: add the contributors' partials in ascending workgroup order
+                bool again = false;
+                while (c1 < nchunk) {
+                    const int s = sk_start(mp.sk, gi);
+                    if (s >= tile_end) break;
+                    int e = sk_start(mp.sk, gi + 1);
+                    e = e < tile_end ? e : tile_end;
+                    if (e > s) {
+                        if (sk_wait(mp.sk, gi, tag, tid, skw)) {
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const f32x4 v = ev_bload4_sc1(rPart, (unsigned)gi * pslot + pelem + (unsigned)(a * 4 + q) * 1024u);
+#pragma unroll
+                                    for (int e2 = 0; e2 < 4; ++e2) acc2[a][0][4 * q + e2] += v[e2];
+                                }
+                        } else {                       // not there in time: spill the running sum, compute that share here
+#pragma unroll
+                            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const f32x4 v = {acc2[a][0][4 * q], acc2[a][0][4 * q + 1], acc2[a][0][4 * q + 2], acc2[a][0][4 * q + 3]};
+                                    ev_bstore4_sc1(rPart, (unsigned)g * pslot + pslot / 2 + pelem + (unsigned)(a * 4 + q) * 1024u, v);
+                                }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            cA = s - t * nchunk; cB = e - t * nchunk;
+                            spilled = true; again = true;
+                            ++gi;
+                            break;
+                        }
+                    }
+                    ++gi;
+                }
+                if (again) {
+                    F0 = ldP(cA * 4 + wave, 0); F1 = ldP(cA * 4 + wave, 1); F2 = ldP(cA * 4 + wave, 2); F3 = ldP(cA * 4 + wave, 3);
+                    F4 = ldP(cA * 4 + wave, 4); F5 = ldP(cA * 4 + wave, 5); F6 = ldP(cA * 4 + wave, 6); F7 = ldP(cA * 4 + wave, 7);
+                    continue;
+                }
+                // ---- epilogue: + residual, * mask, store (the lean epilogue's first barrier also retires the last phase 2's LDS reads)
+                conv_epilogue_lean<2, 1, 1>(p, acc2, smem + wave * (32 * 68), wave * 64, n0, lane);
+                break;
+            }
         }
     }
-    if constexpr (MODE == 0) {
-        // ---- epilogue: + residual, * mask, store (the lean epilogue's first barrier also retires the last phase 2's LDS reads)
-        conv_epilogue_lean<2, 1, 1>(p, acc2, smem + wave * (32 * 68), wave * 64, n0, lane);
-    }
+    if constexpr (MODE == 0) sk_arrive(mp.sk, tag, tid);
 }
 
 // ---------------------------------------------------------------------------

@@ -5,8 +5,9 @@ Mirrors ``feel_me.py:298-317`` (emoji -> speaker, strip emojis / brackets, empty
 ``SPEAKING_RATE = 0.8``, ``STEPS = 10``, ``TTS_TEMPERATURE = 0.667``, ``:70-77``) and ``:181-187`` (``to_waveform``:
 clamp, denoiser at strength 0.00025, copy to the host).  Audio playback (``sounddevice``), ASR and the LLM are out of scope.
 
-The cleaner's phonemiser (espeak-ng) is absent offline, so the text -> ids step is a callable: by default
-``emojivoice_amd.text.text_to_sequence(text, ["english_cleaners2"], phonemize)`` with the caller's ``phonemize``; tests and
+The cleaner's phonemiser (espeak-ng / misaki) is absent offline, so the text -> ids step is a callable: by default
+``emojivoice_amd.text.text_to_sequence(text, [cleaner of ``language``], phonemize)`` with the caller's ``phonemize``
+(en / fr / de / ja as in ``process_text``; "es" raises as the reference's broken ``spanish_cleaners`` does); tests and
 benchmarks pass a stand-in front end that maps the stripped text through the symbol table.
 """
 from __future__ import annotations
@@ -34,11 +35,14 @@ def table_front_end(text: str) -> List[int]:
 
 class EmojiTTS:
     def __init__(self, model, vocoder, denoiser=None, text_to_ids: Optional[Callable[[str], List[int]]] = None,
-                 phonemize: Optional[Callable[[str], str]] = None):
+                 phonemize: Optional[Callable[[str], str]] = None, language: str = "en"):
         self.model, self.vocoder, self.denoiser = model, vocoder, denoiser
+        if language not in T.CLEANER_BY_LANGUAGE:            # feel_me.py:143-145 (the reference prints this and exits)
+            raise ValueError("Invalid language. Current supported languages: en (English), fr (French), ja (Japanese), de (German).")
+        self.language = language
         if text_to_ids is None:
-            def text_to_ids(text, _p=phonemize):          # process_text for LANGUAGE = "en" (feel_me.py:130-147)
-                return T.text_to_sequence(text, ["english_cleaners2"], _p)[0]
+            def text_to_ids(text, _p=phonemize, _c=T.CLEANER_BY_LANGUAGE[language]):   # process_text (feel_me.py:135-147): cleaner by LANGUAGE
+                return T.text_to_sequence(text, [_c], _p)[0]
         self.text_to_ids = text_to_ids
 
     def process_text(self, text: str) -> Dict[str, torch.Tensor]:

@@ -54,23 +54,73 @@ def sequence_to_text(sequence: Sequence[int]) -> str:
 
 # ---- cleaners (cleaners.py), the parts that do not need espeak-ng ----------------------------------------------------
 _whitespace_re = re.compile(r"\s+")
-_ABBREVIATIONS_EN = [(re.compile("\\b%s\\." % a, re.IGNORECASE), b) for a, b in (
-    ("mrs", "misess"), ("ms", "miss"), ("mr", "mister"), ("dr", "doctor"), ("st", "saint"), ("co", "company"), ("jr", "junior"),
-    ("maj", "major"), ("gen", "general"), ("drs", "doctors"), ("rev", "reverend"), ("lt", "lieutenant"), ("hon", "honorable"),
-    ("sgt", "sergeant"), ("capt", "captain"), ("esq", "esquire"), ("ltd", "limited"), ("col", "colonel"), ("ft", "fort"))]
 _ELLIPSIS = "ELLIPSIS_MARKER"
-_REPLACEMENTS_EN = [                                       # cleaners.py:161-174, order matters
-    (re.compile(r"\.\.\."), _ELLIPSIS),
-    (re.compile(r"\$(\d+)\.(\d+)"), r"\1 dollars and \2 cents"),
-    (re.compile(r"€(\d+)\.(\d+)"), r"\1 euros and \2 cents"),
-    (re.compile(r"¥(\d+)\.(\d+)"), r"\1 yen and \2 cents"),
-    (re.compile(r"(?<=\D)\.(?=\D)(?!\s)", re.IGNORECASE), " dot "),
-    (re.compile(r"(?<=\d)\.(?=\d)(?!\s)"), " point "),
-    (re.compile(r"\$(\d+)"), r"\1 dollars"),
-    (re.compile(r"€(\d+)"), r"\1 euros"),
-    (re.compile(r"¥(\d+)"), r"\1 yen"),
-    (re.compile(_ELLIPSIS), "..."),
-]
+
+
+def _abbr(pairs, raw: bool = False):
+    """``\b<abbr>\.`` patterns, case-insensitive (cleaners.py:72-133).  The abbreviation text goes into the pattern UNESCAPED, as in
+    the reference: the dots inside "m.", "z.b", "d.h", "u.a", "u.u", "u.v.m" are regex wildcards there, and list order decides
+    ("z." fires before "z.b." can)."""
+    return [(re.compile("\\b%s\\." % a, re.IGNORECASE), b) for a, b in pairs]
+
+
+_ABBREVIATIONS = {
+    "en": _abbr((("mrs", "misess"), ("ms", "miss"), ("mr", "mister"), ("dr", "doctor"), ("st", "saint"), ("co", "company"),
+                 ("jr", "junior"), ("maj", "major"), ("gen", "general"), ("drs", "doctors"), ("rev", "reverend"), ("lt", "lieutenant"),
+                 ("hon", "honorable"), ("sgt", "sergeant"), ("capt", "captain"), ("esq", "esquire"), ("ltd", "limited"),
+                 ("col", "colonel"), ("ft", "fort"))),
+    "fr": _abbr((("m.", "monsieur"), ("dr", "docteur"), ("st", "saint"))),                                   # cleaners.py:103-110
+    "de": _abbr((("hr", "herr"), ("fr", "frau"), ("dr", "doktor"), ("prof", "professor"), ("bsp", "beispiel"),  # cleaners.py:113-132
+                 ("usw", "und so weiter"), ("z", "zu"), ("z.b", "zum beispiel"), ("ca", "zirka"), ("bzw", "beziehungsweise"),
+                 ("d.h", "das heißt"), ("u.a", "unter anderem"), ("u.u", "unter umständen"), ("u.v.m", "und vieles mehr"),
+                 ("vgl", "vergleiche"))),
+}
+
+
+def _currency_rules(dollar: str, euro: str, yen: str, joiner: str, cents: str, yen_cents: str):
+    """"5.45$" -> "5 <dollar> <joiner> 45 <cents>" (the fr / de tables put the sign AFTER the amount, cleaners.py:180-182, :198-200)."""
+    return [(re.compile(r"(\d+)\.(\d+)\$"), r"\1 %s %s \2 %s" % (dollar, joiner, cents)),
+            (re.compile(r"(\d+)\.(\d+)€"), r"\1 %s %s \2 %s" % (euro, joiner, cents)),
+            (re.compile(r"(\d+)\.(\d+)¥"), r"\1 %s %s \2 %s" % (yen, joiner, yen_cents))]
+
+
+def _continental(dot: str, comma: str, euro: str, yen: str, mme: str, mlle: str, equals: str, slash: str, minus: str, currency):
+    """The shared shape of the fr and de tables (cleaners.py:176-193, :195-212); order matters."""
+    return ([(re.compile(r"\.\.\."), _ELLIPSIS), (re.compile(r"\("), ""), (re.compile(r"\)"), "")] + currency + [
+        (re.compile(r"(?<=\D)\.(?=\D)(?!\s)", re.IGNORECASE), dot),
+        (re.compile(r"(?<=\d)\,(?=\d)(?!\s)"), comma),
+        (re.compile(r"€"), euro), (re.compile(r"¥"), yen),
+        (re.compile(r"Mme"), mme), (re.compile(r"Mlle"), mlle),         # (never fire behind lowercase(): kept, as in the reference)
+        (re.compile(r"="), equals), (re.compile(r"/"), slash),
+        (re.compile(r"-(?=\d)(?!\s)"), minus),
+        (re.compile(_ELLIPSIS), "..."),
+    ])
+
+
+_REPLACEMENTS = {
+    "en": [                                                  # cleaners.py:161-174, order matters
+        (re.compile(r"\.\.\."), _ELLIPSIS),
+        (re.compile(r"\$(\d+)\.(\d+)"), r"\1 dollars and \2 cents"),
+        (re.compile(r"€(\d+)\.(\d+)"), r"\1 euros and \2 cents"),
+        (re.compile(r"¥(\d+)\.(\d+)"), r"\1 yen and \2 cents"),
+        (re.compile(r"(?<=\D)\.(?=\D)(?!\s)", re.IGNORECASE), " dot "),
+        (re.compile(r"(?<=\d)\.(?=\d)(?!\s)"), " point "),
+        (re.compile(r"\$(\d+)"), r"\1 dollars"),
+        (re.compile(r"€(\d+)"), r"\1 euros"),
+        (re.compile(r"¥(\d+)"), r"\1 yen"),
+        (re.compile(_ELLIPSIS), "..."),
+    ],
+    "ja": [                                                  # cleaners.py:135-147
+        (re.compile(r"(?<!\s)\.(?!\s)"), " てん"), (re.compile(r"-(?=\d)"), " えん"), (re.compile(r"%"), " パーセント"),
+        (re.compile(r"@"), " アットマーク"), (re.compile(r"\\\\"), " バックスラッシュ"), (re.compile(r"/"), " スラッシュ"),
+        (re.compile(r"\$"), " ドル"), (re.compile(r"€"), " ユーロ"), (re.compile(r"¥"), " えん"), (re.compile(r"\+"), " プラス"),
+        (re.compile(r"="), " イコール"),
+    ],
+    "fr": _continental(" point ", " vergule ", " euros", " yen", "madame", "mademoiselle", " égales ", " slash ", "négatif ",
+                       _currency_rules("dollars", "euros", "yen", "et", "centimes", "centimes")),
+    "de": _continental(" Punkt ", " Komma ", " Euro", " Yen", "Frau", "Fräulein", " gleich ", " Schrägstrich ", "minus ",
+                       _currency_rules("Dollar", "Euro", "Yen", "und", "Cent", "Sen")),
+}
 
 
 def lowercase(text: str) -> str:
@@ -81,18 +131,30 @@ def collapse_whitespace(text: str) -> str:
     return re.sub(_whitespace_re, " ", text)
 
 
-def expand_abbreviations_en(text: str) -> str:
-    """cleaners.py:219-228 for ``language == "en"``."""
-    for regex, replacement in _ABBREVIATIONS_EN:
+def expand_abbreviations(text: str, language: str) -> str:
+    """cleaners.py:219-228.  A language without a table ("es", "ja") is the reference's ``UnboundLocalError``."""
+    if language not in _ABBREVIATIONS:
+        raise UnboundLocalError("local variable 'abbv' referenced before assignment (no abbreviation table for %r, cleaners.py:219-228)" % language)
+    for regex, replacement in _ABBREVIATIONS[language]:
         text = re.sub(regex, replacement, text)
     return text
 
 
-def apply_replacements_en(text: str) -> str:
-    """cleaners.py:205-217 for ``language == "en"``."""
-    for regex, replacement in _REPLACEMENTS_EN:
+def apply_replacements(text: str, language: str) -> str:
+    """cleaners.py:205-217."""
+    if language not in _REPLACEMENTS:
+        raise UnboundLocalError("local variable 'replacements' referenced before assignment (no replacement table for %r, cleaners.py:205-217)" % language)
+    for regex, replacement in _REPLACEMENTS[language]:
         text = regex.sub(replacement, text)
     return text
+
+
+def expand_abbreviations_en(text: str) -> str:
+    return expand_abbreviations(text, "en")
+
+
+def apply_replacements_en(text: str) -> str:
+    return apply_replacements(text, "en")
 
 
 def basic_cleaners(text: str) -> str:
@@ -100,23 +162,50 @@ def basic_cleaners(text: str) -> str:
     return collapse_whitespace(lowercase(text))
 
 
-def english_cleaners2_pre(text: str) -> str:
-    """The part of ``english_cleaners2`` (cleaners.py:248-254) that runs BEFORE the phonemiser."""
+def _pre_phonemiser(text: str, language: str) -> str:
+    """What english_cleaners2 / french_cleaners / german_cleaners do BEFORE the phonemiser (cleaners.py:248-279); japanese_cleaners
+    (:281-289) only applies its replacement table (no lowercase, no abbreviations)."""
     text = text.encode("utf-8").decode("utf-8")
-    return apply_replacements_en(expand_abbreviations_en(lowercase(text)))
+    if language == "ja":
+        return apply_replacements(text, "ja")
+    return apply_replacements(expand_abbreviations(lowercase(text), language), language)
 
 
-def english_cleaners2(text: str, phonemize: Optional[Callable[[str], str]] = None) -> str:
-    """cleaners.py:248-257.  ``phonemize(text) -> IPA string`` stands for
-    ``EspeakBackend("en-us", preserve_punctuation=True, with_stress=True, language_switch="remove-flags").phonemize([text],
-    strip=True, njobs=1)[0]``; it cannot be provided offline (no espeak-ng), and there is no fallback."""
-    if phonemize is None:
-        raise RuntimeError("english_cleaners2 needs a phonemiser (phonemizer + espeak-ng, cleaners.py:26-61), which this image "
-                           "does not have: pass phonemize=..., or feed pre-phonemised text to cleaned_text_to_sequence")
-    return collapse_whitespace(phonemize(english_cleaners2_pre(text)))
+def english_cleaners2_pre(text: str) -> str:
+    return _pre_phonemiser(text, "en")
 
 
-_CLEANERS = {"basic_cleaners": basic_cleaners, "english_cleaners2": english_cleaners2}
+_NO_PHONEMISER = ("%s needs a phonemiser (phonemizer + espeak-ng / misaki, cleaners.py:26-61), which this image does not have: pass "
+                  "phonemize=..., or feed pre-phonemised text to cleaned_text_to_sequence")
+
+
+def _language_cleaner(name: str, language: str, espeak: str):
+    def cleaner(text: str, phonemize: Optional[Callable[[str], str]] = None) -> str:
+        if phonemize is None:
+            raise RuntimeError(_NO_PHONEMISER % name)
+        return collapse_whitespace(phonemize(_pre_phonemiser(text, language)))
+    cleaner.__name__ = name
+    cleaner.__doc__ = ("cleaners.py: ``phonemize(text) -> IPA string`` stands for the reference's %s backend "
+                       "(preserve_punctuation, with_stress, language_switch='remove-flags'); there is no fallback." % espeak)
+    return cleaner
+
+
+english_cleaners2 = _language_cleaner("english_cleaners2", "en", "EspeakBackend('en-us')")     # cleaners.py:248-257
+french_cleaners = _language_cleaner("french_cleaners", "fr", "EspeakBackend('fr-fr')")         # cleaners.py:259-268
+german_cleaners = _language_cleaner("german_cleaners", "de", "EspeakBackend('de')")            # cleaners.py:270-279
+japanese_cleaners = _language_cleaner("japanese_cleaners", "ja", "misaki ja.JAG2P()")          # cleaners.py:281-289
+
+
+def spanish_cleaners(text: str, phonemize: Optional[Callable[[str], str]] = None) -> str:
+    """cleaners.py:291-300 is broken in the reference (no "es" abbreviation table): the same error, not a guess."""
+    return expand_abbreviations(lowercase(text.encode("utf-8").decode("utf-8")), "es")
+
+
+_CLEANERS = {"basic_cleaners": basic_cleaners, "english_cleaners2": english_cleaners2, "french_cleaners": french_cleaners,
+             "german_cleaners": german_cleaners, "japanese_cleaners": japanese_cleaners, "spanish_cleaners": spanish_cleaners}
+_PHONEMISING = frozenset(_CLEANERS) - {"basic_cleaners"}
+CLEANER_BY_LANGUAGE = {"en": "english_cleaners2", "fr": "french_cleaners", "ja": "japanese_cleaners", "es": "spanish_cleaners",
+                       "de": "german_cleaners"}                         # process_text, feel_me.py:135-141
 
 
 def text_to_sequence(text: str, cleaner_names: Sequence[str], phonemize: Optional[Callable[[str], str]] = None) -> Tuple[List[int], str]:
@@ -124,8 +213,16 @@ def text_to_sequence(text: str, cleaner_names: Sequence[str], phonemize: Optiona
     for name in cleaner_names:
         if name not in _CLEANERS:
             raise Exception("Unknown cleaner: %s" % name)
-        text = _CLEANERS[name](text, phonemize) if name == "english_cleaners2" else _CLEANERS[name](text)
+        text = _CLEANERS[name](text, phonemize) if name in _PHONEMISING else _CLEANERS[name](text)
     return cleaned_text_to_sequence(text), text
+
+
+def process_text_ids(text: str, language: str = "en", phonemize: Optional[Callable[[str], str]] = None) -> List[int]:
+    """The id half of ``process_text`` (feel_me.py:135-147, cli.py:33-59): language -> cleaner -> ids -> ``intersperse(ids, 0)``.
+    An unknown language is a ``ValueError`` (the reference prints a message and exits the process)."""
+    if language not in CLEANER_BY_LANGUAGE:
+        raise ValueError("Invalid language. Current supported languages: en (English), fr (French), ja (Japanese), de (German).")
+    return intersperse(text_to_sequence(text, [CLEANER_BY_LANGUAGE[language]], phonemize)[0], 0)
 
 
 def process_phonemes(phonemes: str, add_blank: bool = True) -> List[int]:

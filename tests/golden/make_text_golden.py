@@ -61,7 +61,27 @@ def main():
         cleaned.append({"text": s, "basic": C.basic_cleaners(s), "english_cleaners2_identity_phonemiser": en2,
                         "expand_abbreviations_en": C.expand_abbreviations(s.lower(), "en"),
                         "apply_replacements_en": C.apply_replacements(s.lower(), "en"), "basic_seq": seq})
-    out = {"symbols_codepoints": [ord(c) for c in symbols], "n_symbols": len(symbols), "space_id": SPACE_ID,
+    # fr / de / ja pre-phonemiser pipelines and the broken es one (cleaners.py:103-147, 176-228, 259-300), phonemiser stand-ins = identity
+    lang_raw = {
+        "fr": ["M.. Dupont (Dr. X) paie 5.45€ et 3,14 = a/b -5 St. Jean... Mme Mlle", "Bonjour   le monde.fr 10.50$ 7.25¥ ¥ €", "M. X et M.Y"],
+        "de": ["Hr. Müller, z.B. 5.45$ usw. d.h. 3,5 = x/y -7 (ok) Prof. u.a. z. B.", "Fr. Dr. Bsp. ca. bzw. u.U. u.v.m. vgl. 9.99€ 1.5¥ Mme",
+               "Guten   Tag.de ... 2,5"],
+        "ja": ["3.14 -5 100% a@b.c 1/2 $5 €6 ¥7 1+1=2 x\\\\y", "こんにちは . 世界.です", "A-B -1"],
+    }
+    fn = {"fr": C.french_cleaners, "de": C.german_cleaners, "ja": C.japanese_cleaners}
+    lang_cases = []
+    for lang, texts in lang_raw.items():
+        for s in texts:
+            rec = {"language": lang, "text": s, "cleaned_identity_phonemiser": fn[lang](s), "apply_replacements": C.apply_replacements(s, lang)}
+            if lang != "ja":
+                rec["expand_abbreviations"] = C.expand_abbreviations(s.lower(), lang)
+            lang_cases.append(rec)
+    try:
+        C.spanish_cleaners("hola")
+        es_error = None
+    except Exception as e:  # noqa: BLE001
+        es_error = type(e).__name__
+    out = {"language_cleaners": lang_cases, "spanish_cleaners_error": es_error, "symbols_codepoints": [ord(c) for c in symbols], "n_symbols": len(symbols), "space_id": SPACE_ID,
            "apostrophe_id": T._symbol_to_id["'"], "cases": cases, "cleaners": cleaned,
            "intersperse": [[[], 0, intersperse([], 0)], [[5], 0, intersperse([5], 0)], [[1, 2, 3], 9, intersperse([1, 2, 3], 9)]]}
     path = os.path.join(HERE, "text_vectors.json")

@@ -63,6 +63,36 @@ def test_emoji_rule_matches_oracle_restatement():
     assert emoji.first_contained_emoji_spk("no emoji") == 12
 
 
+# (character, is an emoji for the `emoji` package) — a fixed table, NOT derived from the product's rule: Unicode emoji-data.txt
+# `Emoji` property.  The first five are the arrow symbols of the reference's phoneme table (matcha/text/symbols.py:9).
+EMOJI_KNOWN = [
+    ("↓", False), ("↑", False), ("→", False), ("↗", True), ("↘", True),
+    ("←", False), ("↔", True), ("↙", True), ("↩", True), ("↪", True), ("↫", False), ("⇒", False),
+    ("☀", True), ("★", False), ("☎", True), ("☐", False), ("☑", True), ("♠", True), ("♡", False),
+    ("✁", False), ("✂", True), ("✓", False), ("✔", True), ("❤", True), ("➔", False), ("➡", True),
+    ("⬅", True), ("⬈", False), ("⭐", True), ("⭑", False), ("©", True), ("™", True), ("a", False),
+    ("1", False), ("#", False), ("(", False), ("ə", False), ("ˈ", False), ("\U0001F60A", True), ("\U0001F923", True),
+    ("\U0001F914", True), ("\U0001F644", True), ("\U0001F1E8", False), ("‍", False), ("️", False), ("\U0001F3FB", True),
+    ("\U0001F322", False), ("\U0001F54F", False), ("\U0001FAF9", False),
+]
+
+
+def test_emoji_property_table_and_sequences():
+    for ch, want in EMOJI_KNOWN:
+        assert emoji._is_emoji_fallback(ch) is want, f"U+{ord(ch):04X}"
+    assert all(emoji._is_emoji_fallback(e) for e in emoji.EMOJI_MAPPING)
+    rep = emoji._replace_emoji_fallback
+    assert rep("a↓↑→b") == "a↓↑→b"                    # phoneme-table arrows survive
+    assert rep("a↗b↘c") == "abc"                                            # ... the two that are emoji do not
+    assert rep("x \U0001F44D\U0001F3FD y") == "x  y"                                  # skin-tone modifier goes with its base
+    assert rep("\U0001F468‍\U0001F469‍\U0001F467!") == "!"                  # ZWJ family: one sequence
+    assert rep("go \U0001F1E8\U0001F1E6 go") == "go  go"                              # flag = two regional indicators
+    assert rep("1️⃣ and 1 #") == " and 1 #"                                 # keycap sequence; bare digit / '#' stay
+    assert rep("❤️ ok") == " ok"                                            # VS16 after a text-default emoji
+    assert rep("café ★ ✓") == "café ★ ✓"                # non-emoji dingbats stay
+    assert emoji.parse_response("(→) ok \U0001F621") == ("→ ok ", 58)
+
+
 def test_text_encoder_host_stage_matches_oracle(matcha_sd, golden):
     from emojivoice_amd.text_encoder import TextEncoder, generate_path, sequence_mask
 

@@ -137,3 +137,50 @@ def test_ln_mlp_fused(eng, rows, M1):
     ref = (x + h @ w2.T + b2) * mask[:, None]
     got = eng.op_ln_mlp(x.cuda(), ln_g.cuda(), ln_b.cuda(), w1, b1, alpha, beta, w2, b2, mask.cuda())
     _close(got, ref, what="ln + ff")
+
+
+def _ln_mlp_case(rows, M1, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, 256, generator=g) * 1.7 + 0.3
+    ln_g, ln_b = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    w1 = torch.randn(M1, 256, generator=g) / 16.0
+    b1 = torch.randn(M1, generator=g) * 0.1
+    alpha, beta = torch.randn(M1, generator=g) * 0.3, torch.randn(M1, generator=g) * 0.3
+    w2 = torch.randn(256, M1, generator=g) / M1 ** 0.5
+    b2 = torch.randn(256, generator=g) * 0.1
+    mask = (torch.rand(rows, generator=g) > 0.2).float()
+    return x, ln_g, ln_b, w1, b1, alpha, beta, w2, b2, mask
+
+
+@pytest.mark.parametrize("rows", [8192 + 808, 16640, 33280])
+def test_ln_mlp_balanced_grid(eng, rows, monkeypatch):
+    """From one 32-row tile per CU up, ln_mlp_kernel runs as a balanced persistent grid (SkCtl in ev_kernels.h): row tiles are
+    split between workgroups along the hidden width and the partial tiles handed over inside the launch.  Checked against plain
+    torch fp32, against a second handle whose owners never wait (EV_SK_SPIN=0: every hand-off takes the recompute path, which must
+    deliver the SAME bits), and launch after launch (the flags carry a device-side epoch, nothing is re-zeroed)."""
+    from emojivoice_amd._lib import Engine
+
+    x, ln_g, ln_b, w1, b1, alpha, beta, w2, b2, mask = _ln_mlp_case(rows, 1024, rows)
+    xn = F.layer_norm(x, (256,), ln_g, ln_b, eps=1e-5)
+    h = xn @ w1.T + b1
+    h = h + (1.0 / (torch.exp(beta) + 0.000000001)) * torch.sin(h * torch.exp(alpha)) ** 2
+    ref = (x + h @ w2.T + b2) * mask[:, None]
+    args = (x.cuda(), ln_g.cuda(), ln_b.cuda(), w1, b1, alpha, beta, w2, b2, mask.cuda())
+    got = eng.op_ln_mlp(*args)
+    _close(got, ref, what="balanced ln + ff")
+    for _ in range(3):
+        assert torch.equal(eng.op_ln_mlp(*args), got)
+    wq = torch.randn(384, 256, generator=torch.Generator().manual_seed(1)) / 16.0
+    _close(eng.op_ln_mlp(x.cuda(), ln_g.cuda(), ln_b.cuda(), wq, None), xn @ wq.T, what="balanced ln + qkv")
+    monkeypatch.setenv("EV_SK_SPIN", "0")
+    e2 = Engine(0)
+    try:
+        assert torch.equal(e2.op_ln_mlp(*args), got), "the recompute path of a timed-out hand-off must deliver the contributor's bits"
+    finally:
+        e2.close()
+    monkeypatch.setenv("EV_NO_SK_BALANCE", "1")
+    e3 = Engine(0)
+    try:
+        _close(e3.op_ln_mlp(*args), got, what="one tile per workgroup vs balanced")
+    finally:
+        e3.close()

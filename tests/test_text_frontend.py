@@ -50,3 +50,33 @@ def test_cleaners(vec):
         T.english_cleaners2("hello")
     with pytest.raises(Exception):
         T.text_to_sequence("x", ["no_such_cleaner"])
+
+
+def test_language_cleaners_and_switch(vec):
+    """fr / de / ja pre-phonemiser pipelines (cleaners.py:103-147, 176-228, 259-289) and the language switch of
+    ``process_text`` (feel_me.py:135-141) against vectors generated from the reference's own cleaners (identity phonemiser)."""
+    ident = lambda t: t   # noqa: E731
+    seen = set()
+    for c in vec["language_cleaners"]:
+        lang, s = c["language"], c["text"]
+        seen.add(lang)
+        cleaner = T._CLEANERS[T.CLEANER_BY_LANGUAGE[lang]]
+        assert cleaner(s, ident) == c["cleaned_identity_phonemiser"], (lang, s)
+        assert T.apply_replacements(s, lang) == c["apply_replacements"]
+        if "expand_abbreviations" in c:
+            assert T.expand_abbreviations(s.lower(), lang) == c["expand_abbreviations"]
+        with pytest.raises(RuntimeError):
+            cleaner(s)                                            # no phonemiser, no guess
+    assert seen == {"fr", "de", "ja"}
+    assert T.CLEANER_BY_LANGUAGE == {"en": "english_cleaners2", "fr": "french_cleaners", "ja": "japanese_cleaners",
+                                     "es": "spanish_cleaners", "de": "german_cleaners"}
+    assert vec["spanish_cleaners_error"] == "UnboundLocalError"   # broken in the reference (cleaners.py:296): same error here
+    with pytest.raises(UnboundLocalError):
+        T.text_to_sequence("hola", ["spanish_cleaners"], ident)
+    with pytest.raises(ValueError):
+        T.process_text_ids("hi", "xx", ident)
+    # the switch feeds the right cleaner: a letters-only phonemiser stand-in keeps the ids inside the table
+    keep = lambda t: "".join(ch for ch in t if ch in T._symbol_to_id)   # noqa: E731
+    assert T.process_text_ids("Dr. X", "en", keep) == T.intersperse(T.cleaned_text_to_sequence("doctor x"), 0)
+    assert T.process_text_ids("Dr. X", "fr", keep) == T.intersperse(T.cleaned_text_to_sequence("docteur x"), 0)
+    assert T.process_text_ids("Dr. X", "de", keep) == T.intersperse(T.cleaned_text_to_sequence("doktor x"), 0)
