@@ -23,6 +23,7 @@ EXPORTS = [
     "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention", "ev_op_ln_mlp", "ev_set_mrf_streams_max",
+    "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out",
 ]
 
 
@@ -81,6 +82,11 @@ def load_library() -> C.CDLL:
     lib.ev_workspace_bytes.argtypes = [vp, i32, i32, i32]
     lib.ev_workspace_bytes.restype = u64
     lib.ev_cfm_decode.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, f32, f32, vp, vp]
+    lib.ev_cfm_decode2.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, vp, f32, f32, vp, vp]
+    lib.ev_reserve.argtypes = [vp, i32, i32, i32, i32, vp]
+    lib.ev_alloc_count.argtypes = [vp]
+    lib.ev_alloc_count.restype = C.c_int64
+    lib.ev_dbg_sk_stats.argtypes = [vp, C.POINTER(C.c_uint32)]
     lib.ev_estimator.argtypes = [vp, vp, vp, vp, vp, f32, i32, i32, vp, vp]
     lib.ev_hifigan.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.ev_text_encoder.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp]
@@ -95,6 +101,7 @@ def load_library() -> C.CDLL:
     lib.ev_op_groupnorm_mish.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ev_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.ev_op_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.ev_op_attn_out.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
     lib.ev_op_ln_mlp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
     for n in EXPORTS:
         getattr(lib, n)  # raises AttributeError if a declared symbol is not exported
@@ -121,11 +128,13 @@ class Engine:
             raise EvLibraryError(f"ev_create failed with code {rc}")
         self.h = h
         self.spk_emb_dim = spk_emb_dim
+        self.mrf_streams_max = int(os.environ.get("EV_MRF_STREAMS_MAX", "16384"))   # the handle's default (ev_create reads the same variable)
 
     def set_mrf_streams_max(self, max_frames: int) -> None:
         """Largest ``hifigan`` call (B*T mel frames) that runs its three ResBlock1 chains on three streams (0 = never)."""
         if self.lib.ev_set_mrf_streams_max(self.h, int(max_frames)) != 0:
             raise EvLibraryError(self.lib.ev_last_error(self.h).decode())
+        self.mrf_streams_max = int(max_frames)
 
     def close(self):
         if getattr(self, "h", None):
@@ -247,6 +256,34 @@ class Engine:
                                            float(out_scale), float(out_shift), out.data_ptr(), _stream_ptr()), "ev_cfm_decode")
         return out
 
+    def cfm_decode2(self, mu, lengths, spk, z, n_steps: int, mel_std: float, mel_mean: float):
+        """(decoder_outputs, mel) of one decode: both reference outputs from the library, no framework kernel in between."""
+        mu, z = self._f32(mu), self._f32(z)
+        B, F, Tp = mu.shape
+        assert F == 80 and z.shape == mu.shape
+        lengths = lengths.to(mu.device, torch.int32).contiguous()
+        spk_p = None
+        if spk is not None:
+            spk = self._f32(spk)
+            spk_p = spk.data_ptr()
+        dec, mel = torch.empty_like(mu), torch.empty_like(mu)
+        self._check(self.lib.ev_cfm_decode2(self.h, mu.data_ptr(), lengths.data_ptr(), spk_p, z.data_ptr(), B, Tp, int(n_steps),
+                                            dec.data_ptr(), float(mel_std), float(mel_mean), mel.data_ptr(), _stream_ptr()), "ev_cfm_decode2")
+        return dec, mel
+
+    def reserve(self, B: int, Tx_max: int = 0, Tp_max: int = 0, T_voc_max: int = 0) -> None:
+        """Pre-size workspace, scratch and staging for batches of B utterances up to these lengths (ev_reserve)."""
+        self._check(self.lib.ev_reserve(self.h, int(B), int(Tx_max), int(Tp_max), int(T_voc_max), _stream_ptr()), "ev_reserve")
+
+    def alloc_count(self) -> int:
+        return int(self.lib.ev_alloc_count(self.h))
+
+    def sk_stats(self):
+        """(balanced launches so far, arrivals of an unfinished one, hand-off waits that ran out) — diagnostic."""
+        out = (C.c_uint32 * 3)()
+        self._check(self.lib.ev_dbg_sk_stats(self.h, out), "ev_dbg_sk_stats")
+        return tuple(int(v) for v in out)
+
     def estimator(self, x, mu, lengths, spk, t: float):
         x, mu = self._f32(x), self._f32(mu)
         B, F, Tp = mu.shape
@@ -350,3 +387,14 @@ class Engine:
         self._check(self.lib.ev_op_attention(self.h, qkv.data_ptr(), lengths.data_ptr(), B, T, heads, out.data_ptr(), _stream_ptr()),
                     "ev_op_attention")
         return out
+
+    def op_attn_out(self, qkv, lengths, w_out, b_out, hid):
+        """attn_out_kernel: hid + Wout . attention(qkv) + bout; qkv (B, T, 384), hid (B, T, 256), lengths (B,)."""
+        qkv, hid = self._f32(qkv), self._f32(hid).clone()
+        B, T, _ = qkv.shape
+        lengths = lengths.to(qkv.device, torch.int32).contiguous()
+        wh = np.ascontiguousarray(w_out.detach().cpu().float().numpy())
+        bh = np.ascontiguousarray(b_out.detach().cpu().float().numpy())
+        self._check(self.lib.ev_op_attn_out(self.h, qkv.data_ptr(), lengths.data_ptr(), B, T, wh.ctypes.data_as(C.c_void_p), bh.ctypes.data_as(C.c_void_p),
+                                            hid.data_ptr(), _stream_ptr()), "ev_op_attn_out")
+        return hid

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -114,12 +115,13 @@ struct ev_handle {
     int max_steps = 64;         // Euler steps the time-grid buffers of the workspace are planned for (grows on demand)
     int* bad_ids_host = nullptr; int* bad_ids_dev = nullptr;   // mapped host word: count of out-of-range token ids seen by ev_text_encoder
     // workspace
-    char* ws = nullptr; size_t ws_bytes = 0; size_t ws_used = 0;
+    char* ws = nullptr; size_t ws_bytes = 0; size_t ws_used = 0; size_t ws_bytes_last = 0;
     int ws_B = -1, ws_Tp = -1, ws_Tv = -1;
     // profiling
     bool prof = false;
     bool fuse_pairs = true;     // EV_FUSE_PAIRS=0 disables resblock_pair_kernel (A/B runs)
     int fuse128 = 3;            // fuse C=128 pairs up to this kernel size (EV_FUSE128=0/3/7/11)
+    bool fuse_attn = true;      // EV_FUSE_ATTN=0: attention and its output projection as separate launches (attention_kernel + a 1x1 conv)
     bool fuse_mlp = true;       // EV_FUSE_MLP=0: LayerNorm / QKV / feed-forward of the transformer blocks as separate launches
     int gn_stats_tiles = 0;         // set by every launch_conv: row tiles whose GroupNorm statistics the launch left in Epi::gn_part (0 = none)
     int fuse_mlp_min_tiles = 96;    // EV_FUSE_MLP_MIN=<32-row tiles>: below this the separate (split-K) launches are used (measured with
@@ -127,6 +129,11 @@ struct ev_handle {
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
     hipStream_t ws_stream = nullptr; bool ws_stream_valid = false;   // stream of the last call that used the workspace
     float* temb_host[2] = {nullptr, nullptr}; size_t temb_cap[2] = {0, 0}; hipEvent_t temb_ev[2] = {nullptr, nullptr}; int temb_slot = 0;
+    // Captured ev_cfm_decode calls stage their time embeddings in pinned memory that is NEVER recycled (a replay reads it whenever
+    // the graph runs): EV_CAPTURE_SLOTS regions of one block allocated by ev_load_estimator, one consumed per captured call.
+    float* cap_pool = nullptr; size_t cap_stride = 0; int cap_used = 0;
+    bool captured = false; int cap_B = 0, cap_Tp = 0;   // a handle with a captured call stays bound to that (B, Tp): see ev_cfm_decode
+    int64_t n_allocs = 0;       // device / pinned allocations made by the hot calls after loading (workspace and scratch growth, staging)
     double prof_flops = 0; int64_t prof_launches = 0;
     struct ProfRec { int kind, Cin, Cout, ntaps, nrows, cfg, lean; double flops; };
     std::vector<ProfRec> prof_recs;   // one per timed launch (EV_PROFILE_DUMP=<file> writes the per-shape table)
@@ -140,6 +147,7 @@ struct ev_handle {
     unsigned* sk_ctrl = nullptr;    // [0] epoch [1] arrivals [2] timed-out waits | flags from word 16 on
     float* sk_part = nullptr;
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
+    int sk_wgs = 2;                 // EV_SK_WGS=<1..3>: persistent workgroups per CU of a balanced ln_mlp launch (A/B runs)
     int sk_spin = 20000;            // EV_SK_SPIN=<polls> before an owner recomputes a contributor's share itself (~1.5 us per poll)
     int mrf_max_frames = 16384;     // EV_MRF_STREAMS_MAX=<B*T mel frames>: calls up to this size use the three streams (0 = never).  Six more scratch
                                     // tensors per level; at batch 64 x 516 frames (21 GB) the two-stage pipeline of bench.py already fills the gaps:
@@ -176,9 +184,11 @@ int scratch_acquire(ev_handle* h, ev_handle::Scratch& s, size_t need) {
     if (need > s.bytes) {
         if (s.last_valid) HIPCHK(h, hipStreamSynchronize(h->stream));
         if (s.p) HIPCHK(h, hipFree(s.p));
-        s.p = nullptr; s.bytes = 0;
-        HIPCHK(h, hipMalloc((void**)&s.p, need));
-        s.bytes = need;
+        const size_t want = std::max(need, s.bytes + s.bytes / 2);      // geometric growth: a stream of ever longer utterances
+        s.p = nullptr; s.bytes = 0;                                     // re-allocates O(log) times, not once per new maximum
+        if (hipMalloc((void**)&s.p, want) == hipSuccess) s.bytes = want;
+        else { (void)hipGetLastError(); HIPCHK(h, hipMalloc((void**)&s.p, need)); s.bytes = need; }
+        ++h->n_allocs;
     }
     s.last = h->stream; s.last_valid = true;
     return 0;
@@ -374,11 +384,15 @@ struct LaunchOpts {
 template <auto Kernel>
 inline void ensure_dyn_smem(size_t smem, int device) {
     static std::atomic<int> granted[16];
+    static std::mutex slow[16];           // the attribute is sticky and NOT monotonic: two threads raising it must not interleave
     const int d = device & 15;
-    if (smem <= 65536 || (int)smem <= granted[d].load(std::memory_order_relaxed)) return;
-    hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    int cur = granted[d].load(std::memory_order_relaxed);
-    while (cur < (int)smem && !granted[d].compare_exchange_weak(cur, (int)smem, std::memory_order_relaxed)) {}
+    if (smem <= 65536 || (int)smem <= granted[d].load(std::memory_order_acquire)) return;
+    std::lock_guard<std::mutex> lk(slow[d]);
+    const int cur = granted[d].load(std::memory_order_relaxed);
+    if ((int)smem <= cur) return;
+    if (hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) == hipSuccess)
+        granted[d].store((int)smem, std::memory_order_release);
+    else (void)hipGetLastError();         // (the launch that follows reports the failure through hipGetLastError)
 }
 
 template <int BM, int BN, int WM, int WN, bool PF, bool FULL, int LEAN, int KB = 1>
@@ -734,6 +748,7 @@ int launch_ln(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const fl
     return 0;
 }
 
+constexpr int EV_CAPTURE_SLOTS = 8;       // captured ev_cfm_decode calls a handle can hold (pinned staging that is never recycled)
 constexpr int EV_SK_MAXWG = 1024;          // persistent workgroups of a balanced launch (<= 4 per CU on 256 CUs)
 constexpr int EV_SK_PART_FLOATS = 16384;   // largest partial accumulator tile handed over (64 KB: a 64 x 192 conv tile is 48 KB)
 // Hand-off area of the balanced launches: allocated once per handle (never inside a stream capture: ev_load_estimator calls this)
@@ -780,13 +795,17 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
     int grid = ntiles;
     mp.ntiles = ntiles;
     mp.sk.q = nchunk; mp.sk.r = 0; mp.sk.spin_limit = h->sk_spin;
-    if (h->sk_balance && h->ncu > 0 && ntiles >= h->ncu && 3 * h->ncu <= EV_SK_MAXWG && (long)ntiles * nchunk >= 3L * h->ncu) {
+    const int wpc = h->sk_wgs;
+    if (h->sk_balance && h->ncu > 0 && ntiles >= h->ncu && wpc * h->ncu <= EV_SK_MAXWG && (long)ntiles * nchunk >= (long)wpc * h->ncu) {
         if (ensure_sk(h)) return 1;
-        grid = 3 * h->ncu;
+        grid = wpc * h->ncu;
         const long U = (long)ntiles * nchunk;
         mp.sk.q = (int)(U / grid); mp.sk.r = (int)(U % grid);
         mp.sk.ctrl = h->sk_ctrl; mp.sk.flags = h->sk_ctrl + 16; mp.sk.part = h->sk_part; mp.sk.part_floats = EV_SK_PART_FLOATS;
-        smem = std::max(smem, (size_t)((160 * 1024 / 3) & ~255));
+        // three per CU: the LDS request is padded so that exactly three fit.  Two per CU (the default): the 256-register build admits
+        // exactly two workgroups per CU by itself, and the un-padded request leaves LDS for the workgroups of another stream (the
+        // vocoder of the previous batch in the pipelined schedule) instead of locking them out of the CU.
+        if (wpc != 2) smem = std::max(smem, (size_t)((160 * 1024 / wpc) & ~255));
     }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
@@ -796,8 +815,13 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
         e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
-    if (mode == 0) hipLaunchKernelGGL(ln_mlp_kernel<0>, dim3(grid), dim3(256), smem, h->stream, mp);
-    else hipLaunchKernelGGL(ln_mlp_kernel<1>, dim3(grid), dim3(256), smem, h->stream, mp);
+    // the balanced grid at two workgroups per CU has its own build (256 registers, no spills); so has every launch of at most two
+    // tiles per CU (small batches: one tile per workgroup, at most two of them on a CU)
+    const bool two = (mp.sk.ctrl != nullptr && wpc == 2) || (mp.sk.ctrl == nullptr && h->ncu > 0 && ntiles <= 2 * h->ncu);
+    if (mode == 0 && two) { ensure_dyn_smem<ln_mlp_kernel<0, 2>>(smem, h->device); hipLaunchKernelGGL((ln_mlp_kernel<0, 2>), dim3(grid), dim3(256), smem, h->stream, mp); }
+    else if (mode == 0) { ensure_dyn_smem<ln_mlp_kernel<0, 3>>(smem, h->device); hipLaunchKernelGGL((ln_mlp_kernel<0, 3>), dim3(grid), dim3(256), smem, h->stream, mp); }
+    else if (two) { ensure_dyn_smem<ln_mlp_kernel<1, 2>>(smem, h->device); hipLaunchKernelGGL((ln_mlp_kernel<1, 2>), dim3(grid), dim3(256), smem, h->stream, mp); }
+    else { ensure_dyn_smem<ln_mlp_kernel<1, 3>>(smem, h->device); hipLaunchKernelGGL((ln_mlp_kernel<1, 3>), dim3(grid), dim3(256), smem, h->stream, mp); }
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
         HIPCHK(h, hipEventRecord(e1, h->stream));
@@ -831,6 +855,46 @@ int launch_attn(ev_handle* h, const float* QKV, int ld, float* O, int ldo, const
         hipLaunchKernelGGL(attention_kernel, dim3((g.T + 127) / 128, H, g.nrows / g.S), dim3(256), 0, h->stream, p);
     }
     HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+// attention of both heads + output projection + residual in one launch (attn_out_kernel): H += Wout . attn(QKV) + bout, in place.
+// Counted as ONE launch of the dominant-kernel family by the profiling hooks (its FLOPs: QK^T and PV of both heads + the projection).
+inline bool attn_out_ok(const ev_handle* h, const ConvLayer& Lo, const Geom& g, int H) {
+    const long wgs = (long)((g.T + 31) / 32) * (g.nrows / g.S);
+    return h->fuse_attn && H == 2 && Lo.Cin == 128 && Lo.Kpad == 128 && Lo.Cout == 256 && Lo.Mpad == 256 && Lo.ntaps == 1 && !Lo.sparse_taps && Lo.bias &&
+           g.S >= 4 && h->ncu > 0 && wgs >= h->ncu / 2;
+}
+int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo, float* Hid, int ldh, const float* rowmask, const Geom& g, int H) {
+    AttnOutParams p;
+    memset(&p, 0, sizeof p);
+    const int B = g.nrows / g.S;
+    p.QKV = QKV; p.ld = ld; p.rowmask = rowmask; p.Wout = Lo.W; p.S = g.S; p.P = g.P; p.T = g.T; p.B = B; p.nq = (g.T + 31) / 32; p.scale = 0.125f;
+    p.xcd_map = (B % 8 == 0) ? 1 : 0;
+    ConvParams& e = p.ep;
+    e.Y = Hid; e.ldy = ldh; e.Cout = Lo.Cout; e.bias = Lo.bias; e.R = Hid; e.ldr = ldh; e.osplit_log2 = 31; e.isplit_log2 = 31; e.mmul = 1; e.scale = 1.f;
+    e.nrows = g.nrows; e.S = g.S; e.P = g.P; e.T = g.T;
+    if ((ldh & 3) || (ld & 3) || ((size_t)Lo.bias & 15)) return fail(h, "launch_attn_out: unaligned operand");
+    if ((double)g.nrows * std::max(ld, ldh) * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
+    const size_t smem = (size_t)4 * 2 * 32 * AO_LDK * sizeof(float);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t ev; HIPCHK(h, hipEventCreate(&ev)); h->ev_pool.push_back(ev); }
+        }
+        e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+    }
+    ensure_dyn_smem<attn_out_kernel>(smem, h->device);
+    hipLaunchKernelGGL(attn_out_kernel, dim3((unsigned)(p.nq * B)), dim3(256), smem, h->stream, p);
+    HIPCHK(h, hipGetLastError());
+    if (h->prof) {
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        const double fl = (double)B * ((double)H * 4.0 * g.T * (double)g.T * 64.0 + 2.0 * Lo.macs_per_row * g.T);
+        h->prof_flops += fl;
+        h->prof_launches += 1;
+        h->prof_recs.push_back({4, 128, 256, 1, g.nrows, 30, 1, fl});
+    }
     return 0;
 }
 
@@ -924,6 +988,21 @@ size_t plan_all(ev_handle* h, char* base, int B, int Tp, int Tv, EstBufs* eb, Vo
     return b.off;
 }
 
+// Replace the arena by one of at least `need` bytes.  Growth on the request path is geometric (x1.5): a stream of utterances with ever
+// new maximum lengths re-allocates O(log) times; ev_reserve sizes it once up front (exact).
+int grow_ws(ev_handle* h, size_t need, bool geometric) {
+    if (h->ws_stream_valid) HIPCHK(h, hipStreamSynchronize(h->ws_stream));
+    if (h->stream && (!h->ws_stream_valid || h->stream != h->ws_stream)) HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->ws) HIPCHK(h, hipFree(h->ws));
+    h->ws = nullptr; h->ws_bytes = 0; h->ws_B = -1;
+    const size_t want = geometric ? std::max(need, h->ws_bytes_last + h->ws_bytes_last / 2) : need;
+    if (want > need && hipMalloc((void**)&h->ws, want) == hipSuccess) h->ws_bytes = want;
+    else { (void)hipGetLastError(); HIPCHK(h, hipMalloc((void**)&h->ws, need)); h->ws_bytes = need; }
+    h->ws_bytes_last = h->ws_bytes;
+    ++h->n_allocs;
+    return 0;
+}
+
 // make sure the arena fits (B, Tp, Tv); zero it when the geometry changes (pad rows must be zero)
 int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
     // keep the other path's last shape so alternating cfm/hifigan calls do not thrash
@@ -936,11 +1015,9 @@ int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
     const size_t need = plan_all(h, nullptr, B, Tp, Tv, nullptr, nullptr);
     bool rezero = (B != h->ws_B || Tp != h->ws_Tp || Tv != h->ws_Tv);
     if (need > h->ws_bytes) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (h->ws) HIPCHK(h, hipFree(h->ws));
-        h->ws = nullptr; h->ws_bytes = 0;
-        HIPCHK(h, hipMalloc((void**)&h->ws, need));
-        h->ws_bytes = need;
+        if (h->captured) return fail(h, "this handle holds a captured ev_cfm_decode: its workspace cannot be replaced (needs %zu bytes, has %zu); "
+                                        "use ev_reserve before capturing, or another handle", need, h->ws_bytes);
+        if (grow_ws(h, need, true)) return 1;
         rezero = true;
     }
     size_t voc_off = 0;
@@ -1009,9 +1086,13 @@ int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z,
         if (launch_ln(h, L.H, 256, L.LN, 256, w.ln1g, w.ln1b, L.g)) return 1;
         if (launch_conv(h, w.qkv, L.LN, 256, L.QKV, 384, L.g, e)) return 1;
     }
-    if (launch_attn(h, L.QKV, 384, L.ATT, 128, L.rm, L.g, heads, L.ATTP)) return 1;
-    Epi eo; eo.R = L.H; eo.ldr = 256;
-    if (launch_conv(h, w.out, L.ATT, 128, L.H, 256, L.g, eo)) return 1;  // H <- attn + H (in place, element-wise aliasing only)
+    if (attn_out_ok(h, w.out, L.g, heads)) {
+        if (launch_attn_out(h, L.QKV, 384, w.out, L.H, 256, L.rm, L.g, heads)) return 1;   // H <- H + Wout . attn + b, one launch
+    } else {
+        if (launch_attn(h, L.QKV, 384, L.ATT, 128, L.rm, L.g, heads, L.ATTP)) return 1;
+        Epi eo; eo.R = L.H; eo.ldr = 256;
+        if (launch_conv(h, w.out, L.ATT, 128, L.H, 256, L.g, eo)) return 1;  // H <- attn + H (in place, element-wise aliasing only)
+    }
     if (fuse) return launch_mlp(h, 0, L.H, w.ln3g, w.ln3b, w.ff1, &w.ff2, w.alpha, w.binv, L.H, L.rm, Z, ldz, L.g);
     if (launch_ln(h, L.H, 256, L.LN, 256, w.ln3g, w.ln3b, L.g)) return 1;
     Epi e1; e1.act = ACT_SNAKE; e1.act_a = w.alpha; e1.act_b = w.binv;
@@ -1081,22 +1162,36 @@ int run_time_mlp(ev_handle* h, EstBufs& b, const std::vector<float>& ts) {
         }
     }
     {   // staged through a two-slot pinned ring owned by the handle: no host/stream synchronisation per call, so a caller
-        // that pipelines consecutive batches on two streams (emojivoice_amd/pipeline.py) keeps enqueueing ahead of the GPU
+        // that pipelines consecutive batches on two streams (emojivoice_amd/pipeline.py) keeps enqueueing ahead of the GPU.
+        // A call under stream capture gets a region of the capture pool instead, which is never written again: a replay may
+        // read it at any later time, whatever eager calls (other n_steps, other ring contents) happen in between.
         const size_t bytes = emb.size() * sizeof(float);
         hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
         const bool capturing = h->stream && hipStreamIsCapturing(h->stream, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive;
-        const int slot = (h->temb_slot ^= 1);
-        if (h->temb_cap[slot] < bytes) {
-            if (h->temb_host[slot]) { HIPCHK(h, hipEventSynchronize(h->temb_ev[slot])); HIPCHK(h, hipHostFree(h->temb_host[slot])); }
-            HIPCHK(h, hipHostMalloc((void**)&h->temb_host[slot], bytes, hipHostMallocDefault));
-            h->temb_cap[slot] = bytes;
-            if (!h->temb_ev[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->temb_ev[slot], hipEventDisableTiming));
-        } else if (!capturing) {
-            HIPCHK(h, hipEventSynchronize(h->temb_ev[slot]));   // the copy issued two calls ago has read this slot
+        const float* src = nullptr;
+        if (capturing) {
+            if (!h->cap_pool || bytes > h->cap_stride) return fail(h, "ev_cfm_decode under stream capture: %d Euler steps exceed the capture staging (%zu bytes per call)", nt, h->cap_stride);
+            if (h->cap_used >= EV_CAPTURE_SLOTS) return fail(h, "ev_cfm_decode under stream capture: this handle has already captured %d calls (their staging is never recycled)", EV_CAPTURE_SLOTS);
+            float* dst = (float*)((char*)h->cap_pool + (size_t)h->cap_used++ * h->cap_stride);
+            memcpy(dst, emb.data(), bytes);
+            src = dst;
+        } else {
+            const int slot = (h->temb_slot ^= 1);
+            if (h->temb_cap[slot] < bytes) {
+                if (h->temb_host[slot]) { HIPCHK(h, hipEventSynchronize(h->temb_ev[slot])); HIPCHK(h, hipHostFree(h->temb_host[slot])); h->temb_host[slot] = nullptr; h->temb_cap[slot] = 0; }
+                const size_t want = std::max(bytes, (size_t)64 * dim * sizeof(float));
+                HIPCHK(h, hipHostMalloc((void**)&h->temb_host[slot], want, hipHostMallocDefault));
+                h->temb_cap[slot] = want;
+                ++h->n_allocs;
+                if (!h->temb_ev[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->temb_ev[slot], hipEventDisableTiming));
+            } else {
+                HIPCHK(h, hipEventSynchronize(h->temb_ev[slot]));   // the copy issued two calls ago has read this slot
+            }
+            memcpy(h->temb_host[slot], emb.data(), bytes);
+            src = h->temb_host[slot];
         }
-        memcpy(h->temb_host[slot], emb.data(), bytes);
-        HIPCHK(h, hipMemcpyAsync(b.temb_in, h->temb_host[slot], bytes, hipMemcpyHostToDevice, h->stream));
-        if (!capturing) HIPCHK(h, hipEventRecord(h->temb_ev[slot], h->stream));
+        HIPCHK(h, hipMemcpyAsync(b.temb_in, src, bytes, hipMemcpyHostToDevice, h->stream));
+        if (!capturing) HIPCHK(h, hipEventRecord(h->temb_ev[h->temb_slot], h->stream));
     }
     Geom gt{nt, nt, 0, nt};
     Epi e1; e1.act = ACT_SILU;
@@ -1326,10 +1421,12 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     { const char* fp = getenv("EV_FUSE_PAIRS"); if (fp && *fp == '0') h->fuse_pairs = false; }
     { const char* fp = getenv("EV_FUSE128"); if (fp && *fp) h->fuse128 = atoi(fp); }
     { const char* fp = getenv("EV_FUSE_MLP"); if (fp && *fp == '0') h->fuse_mlp = false; }
+    { const char* fp = getenv("EV_FUSE_ATTN"); if (fp && *fp == '0') h->fuse_attn = false; }
     { const char* fp = getenv("EV_FUSE_MLP_MIN"); if (fp && *fp) h->fuse_mlp_min_tiles = atoi(fp); }
     { const char* fp = getenv("EV_MRF_STREAMS_MAX"); if (fp && *fp) h->mrf_max_frames = atoi(fp); }
     { const char* fp = getenv("EV_NO_SK_BALANCE"); if (fp && *fp && *fp != '0') h->sk_balance = false; }
     { const char* fp = getenv("EV_SK_SPIN"); if (fp && *fp) h->sk_spin = atoi(fp); }
+    { const char* fp = getenv("EV_SK_WGS"); if (fp && *fp) h->sk_wgs = std::min(3, std::max(1, atoi(fp))); }
     if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) h->ncu = 0;
     // the shipped decoder configuration (configs/model/decoder/default.yaml: 2 heads x 64) is the only one the workspace
     // plan and the transformer launch sequence are laid out for
@@ -1347,6 +1444,7 @@ void ev_destroy(ev_handle* h) {
     hipDeviceSynchronize();
     for (void* p : h->owned) hipFree(p);
     if (h->ws) hipFree(h->ws);
+    if (h->cap_pool) hipHostFree(h->cap_pool);
     if (h->sk_ctrl) hipFree(h->sk_ctrl);
     if (h->sk_part) hipFree(h->sk_part);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
@@ -1473,6 +1571,15 @@ int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* in
         REQ(pack_conv(h, w.fin_proj, *pw, pb, 1));
         REQ(upload_vec(h, m, "final_block.block.1.weight", &w.fin_g));
         REQ(upload_vec(h, m, "final_block.block.1.bias", &w.fin_b));
+    }
+    if (!h->zeros) {      // stand-in bias of the fused kernels' unconditional loads (a layer without bias reads zeros)
+        HIPCHK(h, hipMalloc((void**)&h->zeros, 4096 * sizeof(float)));
+        HIPCHK(h, hipMemset(h->zeros, 0, 4096 * sizeof(float)));
+        h->owned.push_back(h->zeros);
+    }
+    if (!h->cap_pool) {   // pinned staging of captured ev_cfm_decode calls (see run_time_mlp): EV_CAPTURE_SLOTS x (64 steps x in_ch floats)
+        h->cap_stride = ((size_t)64 * w.in_ch * sizeof(float) + 255) & ~(size_t)255;
+        HIPCHK(h, hipHostMalloc((void**)&h->cap_pool, h->cap_stride * EV_CAPTURE_SLOTS, hipHostMallocDefault));
     }
     w.loaded = true;
     return 0;
@@ -1652,16 +1759,31 @@ static int check_cfm_args(ev_handle* h, int B, int Tp) {
     return 0;
 }
 
-int ev_cfm_decode(ev_handle* h, const float* d_mu, const int32_t* d_lengths, const float* d_spk, const float* d_z,
-                  int B, int Tp, int n_steps, float out_scale, float out_shift, float* d_out, void* stream) {
+static int cfm_decode_impl(ev_handle* h, const float* d_mu, const int32_t* d_lengths, const float* d_spk, const float* d_z,
+                           int B, int Tp, int n_steps, float* d_dec, float out_scale, float out_shift, float* d_out, void* stream) {
     if (!h) return 1;
     HIPCHK(h, hipSetDevice(h->device));
     if (check_cfm_args(h, B, Tp)) return 1;
     if (n_steps <= 0 || n_steps > 65536) return fail(h, "n_steps %d must be positive (cli.py:143) and at most 65536", n_steps);
-    // the reference has no upper limit on n_timesteps: the per-step time-embedding buffers are re-planned when a call asks for more
-    while (n_steps > h->max_steps) { h->max_steps *= 2; h->ws_B = -1; }
-    if (!d_mu || !d_z || !d_out || (h->dims.spk_emb_dim > 0 && !d_spk)) return fail(h, "null tensor argument");
+    if (!d_mu || !d_z || (!d_out && !d_dec) || (h->dims.spk_emb_dim > 0 && !d_spk)) return fail(h, "null tensor argument");
     h->stream = (hipStream_t)stream;
+    hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+    const bool capturing = h->stream && hipStreamIsCapturing(h->stream, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive;
+    // A captured call's kernels address the workspace as planned for its (B, Tp): from then on the handle only accepts that shape
+    // (another shape would re-plan and re-zero the arena under the graph), and nothing that would replace the arena.
+    if (h->captured && (B != h->cap_B || Tp != h->cap_Tp))
+        return fail(h, "this handle holds a captured ev_cfm_decode at (B=%d, Tp=%d): calls at (B=%d, Tp=%d) need another handle", h->cap_B, h->cap_Tp, B, Tp);
+    if (n_steps > h->max_steps) {
+        // the reference has no upper limit on n_timesteps: the per-step time-embedding buffers are re-planned when a call asks for more
+        if (h->captured || capturing) return fail(h, "n_steps %d exceeds the %d the workspace is planned for and the handle is captured / capturing: call once eagerly first", n_steps, h->max_steps);
+        while (n_steps > h->max_steps) h->max_steps *= 2;
+        h->ws_B = -1;
+    }
+    if (capturing) {
+        if (B != h->ws_B || Tp != h->ws_Tp || plan_all(h, nullptr, B, Tp, h->ws_Tv > 0 ? h->ws_Tv : 0, nullptr, nullptr) > h->ws_bytes)
+            return fail(h, "ev_cfm_decode under stream capture needs a prior eager call at (B=%d, Tp=%d) on this handle (workspace planning allocates and zeroes)", B, Tp);
+        h->captured = true; h->cap_B = B; h->cap_Tp = Tp;
+    }
     EstBufs b;
     if (ensure_ws(h, B, Tp, 0, &b, nullptr)) return 1;
     // time grid exactly as torch.linspace(0, 1, n+1) + the running t / dt of solve_euler (flow_matching.py:52,70-83), in fp32
@@ -1686,8 +1808,79 @@ int ev_cfm_decode(ev_handle* h, const float* d_mu, const int32_t* d_lengths, con
     for (int s = 0; s < n_steps; ++s)
         if (run_estimator(h, b, s, dts[s], true)) return 1;
     dim3 grid((Tp + 31) / 32, (80 + 31) / 32, B);
-    hipLaunchKernelGGL(fm_to_cm_kernel, grid, dim3(256), 0, h->stream, (const float*)b.state, 80, 0, d_out, 80, Tp, b.g0.S, b.g0.P, out_scale, out_shift);
+    if (d_dec) hipLaunchKernelGGL(fm_to_cm_kernel, grid, dim3(256), 0, h->stream, (const float*)b.state, 80, 0, d_dec, 80, Tp, b.g0.S, b.g0.P, 1.0f, 0.0f);
+    if (d_out) hipLaunchKernelGGL(fm_to_cm_kernel, grid, dim3(256), 0, h->stream, (const float*)b.state, 80, 0, d_out, 80, Tp, b.g0.S, b.g0.P, out_scale, out_shift);
     HIPCHK(h, hipGetLastError());
+    return 0;
+}
+
+int ev_cfm_decode(ev_handle* h, const float* d_mu, const int32_t* d_lengths, const float* d_spk, const float* d_z,
+                  int B, int Tp, int n_steps, float out_scale, float out_shift, float* d_out, void* stream) {
+    if (h && !d_out) return fail(h, "null tensor argument");
+    return cfm_decode_impl(h, d_mu, d_lengths, d_spk, d_z, B, Tp, n_steps, nullptr, out_scale, out_shift, d_out, stream);
+}
+
+int ev_cfm_decode2(ev_handle* h, const float* d_mu, const int32_t* d_lengths, const float* d_spk, const float* d_z,
+                   int B, int Tp, int n_steps, float* d_dec, float mel_std, float mel_mean, float* d_mel, void* stream) {
+    return cfm_decode_impl(h, d_mu, d_lengths, d_spk, d_z, B, Tp, n_steps, d_dec, mel_std, mel_mean, d_mel, stream);
+}
+
+int ev_reserve(ev_handle* h, int B, int Tx_max, int Tp_max, int T_voc_max, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (B <= 0 || Tx_max < 0 || Tp_max < 0 || T_voc_max < 0 || (Tp_max & 3)) return fail(h, "ev_reserve: bad shape B=%d Tx=%d Tp=%d (multiple of 4) T_voc=%d", B, Tx_max, Tp_max, T_voc_max);
+    h->stream = (hipStream_t)stream;
+    if (Tp_max > 0 || T_voc_max > 0) {
+        // the plan is monotonic in every argument except for the three-stream scratch of small vocoder calls: take the larger
+        size_t need = plan_all(h, nullptr, B, Tp_max, T_voc_max, nullptr, nullptr);
+        if (T_voc_max > 0 && h->mrf_max_frames > 0) {
+            const int tv_ms = (int)std::min<long>(T_voc_max, h->mrf_max_frames / B);
+            if (tv_ms > 0) need = std::max(need, plan_all(h, nullptr, B, Tp_max, tv_ms, nullptr, nullptr));
+        }
+        if (need > h->ws_bytes) {
+            if (h->captured) return fail(h, "ev_reserve: this handle holds a captured ev_cfm_decode, its workspace cannot be replaced");
+            if (grow_ws(h, need, false)) return 1;
+        }
+    }
+    if (Tx_max > 0 && h->enc.loaded) {
+        const size_t n = (size_t)B * (Tx_max + 4);
+        const TextEncW& w = h->enc;
+        const size_t need = (n * (1 + 3 * w.nch + 3 * w.C + 2 * w.dp1.Cout + 3 * w.C + w.C + w.ffc + 80 + 4) + 1024) * sizeof(float);
+        if (scratch_acquire(h, h->enc_ws, need)) return 1;
+    }
+    if (T_voc_max > 0) {   // denoiser scratch for L = 256 * T_voc_max (run_denoiser)
+        const size_t n = (size_t)B * (T_voc_max + 4 + 8);
+        const size_t need = (n * (256 + 1032 + 256) + 1024) * sizeof(float);
+        if (scratch_acquire(h, h->dn_ws, need)) return 1;
+        if (denoiser_init(h)) return 1;
+    }
+    if (h->est.loaded) {   // both slots of the pinned time-embedding ring, for the Euler steps the workspace is planned for
+        const size_t bytes = (size_t)std::max(64, h->max_steps) * h->est.in_ch * sizeof(float);
+        for (int slot = 0; slot < 2; ++slot) {
+            if (h->temb_cap[slot] >= bytes) continue;
+            if (h->temb_host[slot]) { HIPCHK(h, hipEventSynchronize(h->temb_ev[slot])); HIPCHK(h, hipHostFree(h->temb_host[slot])); h->temb_host[slot] = nullptr; h->temb_cap[slot] = 0; }
+            HIPCHK(h, hipHostMalloc((void**)&h->temb_host[slot], bytes, hipHostMallocDefault));
+            h->temb_cap[slot] = bytes;
+            if (!h->temb_ev[slot]) HIPCHK(h, hipEventCreateWithFlags(&h->temb_ev[slot], hipEventDisableTiming));
+            HIPCHK(h, hipEventRecord(h->temb_ev[slot], h->stream));
+        }
+    }
+    if (h->voc.loaded && h->mrf_max_frames > 0 && !h->mrf_stream[0]) {   // streams / events of the three-chain fan-out
+        for (int c = 0; c < 2; ++c) HIPCHK(h, hipStreamCreateWithFlags(&h->mrf_stream[c], hipStreamNonBlocking));
+        for (int c = 0; c < 4; ++c) HIPCHK(h, hipEventCreateWithFlags(&h->mrf_ev[c], hipEventDisableTiming));
+    }
+    return 0;
+}
+
+int64_t ev_alloc_count(ev_handle* h) { return h ? h->n_allocs : -1; }
+
+int ev_dbg_sk_stats(ev_handle* h, uint32_t* out3) {
+    if (!h || !out3) return 1;
+    out3[0] = out3[1] = out3[2] = 0;
+    if (!h->sk_ctrl) return 0;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out3, h->sk_ctrl, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return 0;
 }
 
@@ -2082,6 +2275,34 @@ int ev_op_attention(ev_handle* h, const float* d_qkv, const int32_t* d_lengths, 
     int rc = launch_attn(h, d_qkv, 3 * heads * 64, d_out, heads * 64, rm, g, heads);
     hipStreamSynchronize(h->stream);
     hipFree(rm);
+    return rc;
+}
+
+// attn_out_kernel: d_hid (B*T, 256) <- d_hid + Wout . attention(d_qkv) + bout; w_out (256, 128), b_out (256) are HOST pointers
+int ev_op_attn_out(ev_handle* h, const float* d_qkv, const int32_t* d_lengths, int B, int T, const float* w_out, const float* b_out, float* d_hid, void* stream) {
+    if (!h) return 1;
+    HIPCHK(h, hipSetDevice(h->device));
+    h->stream = (hipStream_t)stream;
+    if (B <= 0 || T <= 0 || !d_qkv || !w_out || !b_out || !d_hid) return fail(h, "ev_op_attn_out: bad arguments");
+    size_t owned0 = h->owned.size();
+    ConvLayer Lo;
+    HostTensor tw, tb;
+    tw.p = w_out; tw.ndim = 2; tw.shape[0] = 256; tw.shape[1] = 128;
+    tb.p = b_out; tb.ndim = 1; tb.shape[0] = 256;
+    int rc = pack_linear_stack(h, Lo, {&tw}, {&tb});
+    Geom g{B * T, T, 0, T};
+    float* rm = nullptr;
+    if (!rc && hipMalloc((void**)&rm, (size_t)g.nrows * 4) != hipSuccess) rc = fail(h, "ev_op_attn_out: out of memory");
+    if (!rc) {
+        hipLaunchKernelGGL(rowmask_kernel, dim3((g.nrows + 255) / 256), dim3(256), 0, h->stream, rm, d_lengths, g.nrows, g.S, g.P, g.T, 1);
+        rc = launch_attn_out(h, d_qkv, 384, Lo, d_hid, 256, rm, g, 2);
+    }
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, "sync failed");
+    if (rm) hipFree(rm);
+    while (h->owned.size() > owned0) {
+        if (h->owned.back() == (void*)h->zeros) break;
+        hipFree(h->owned.back()); h->owned.pop_back();
+    }
     return rc;
 }
 

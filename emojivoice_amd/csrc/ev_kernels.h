@@ -1546,7 +1546,9 @@ __device__ __forceinline__ bool sk_wait(const SkCtl& c, int gi, unsigned tag, in
         *word = ok;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const bool ok = *word != 0;
+    // (readfirstlane: the result steers wave-uniform control flow — chunk ranges, hence descriptor offsets of the fragment loads;
+    // read as a plain LDS value it made hipcc treat all of that as divergent and wrap every buffer load of the K loops in a waterfall loop)
+    const bool ok = __builtin_amdgcn_readfirstlane(*word) != 0;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (the word may be rewritten by the next wait)
     return ok;
 }
@@ -1573,8 +1575,12 @@ struct MlpParams {
 
 // unit = (32-row tile, 128-wide chunk of the hidden [MODE 1: output] width); a workgroup walks its unit range tile segment by tile
 // segment: stage + LayerNorm the tile's rows once per segment, then the chunks [c0, c1) of it.
-template <int MODE>   // (LDS admits three workgroups per CU: keep the register allocation at three waves per SIMD)
-__global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
+// WPC = workgroups per CU the build is meant for: 3 for the one-tile-per-workgroup grid (LDS admits three: the register allocation
+// stays at three waves per SIMD), 2 for the balanced persistent grid (measured with tools/shape_profile.py, EV_SK_WGS: two
+// workgroups of ~8 units each beat three of ~5.4 — fewer split tiles, fewer staging episodes — and 256 registers leave room to
+// fetch a contributor's partial tile under the last chunk's MFMAs).
+template <int MODE, int WPC>
+__global__ __launch_bounds__(256, WPC) void ln_mlp_kernel(const MlpParams mp) {
     constexpr int NT = 32, C = 256, XLD = C + 4, HC = 128, HLD = HC + 4;
     const ConvParams& p = mp.ep;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1610,6 +1616,7 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
     const __amdgpu_buffer_rsrc_t rPart = ev_rsrc(mp.sk.part);
     const unsigned pslot = (unsigned)mp.sk.part_floats * 8u;            // bytes per workgroup (two tiles)
     const unsigned pelem = (unsigned)(wave * 8) * 1024u + wlane;
+    bool pend_pub = false;                             // partial stored, flag not raised yet (raised behind the next staging's loads)
 
     while (u < ue) {
         const int t = u / nchunk, c0 = u - t * nchunk;
@@ -1640,7 +1647,10 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
                 *(f32x4*)(Xs + r * XLD + c4) = xv[q];
             }
         }
-        ev_lds_barrier();
+        if (pend_pub) {   // every wave has consumed staging loads issued AFTER its partial stores (vmcnt retires in order): the partial
+            sk_publish(mp.sk, g, tag, tid);   // tile is written, raise the flag — the drain in sk_publish finds nothing left to wait for
+            pend_pub = false;
+        } else ev_lds_barrier();
         {   // ---- LayerNorm in place: wave w owns rows 8w .. 8w+7, one row = 4 channels per lane
             const f32x4 gm = *(const f32x4*)(mp.ln_g + lane * 4), be = *(const f32x4*)(mp.ln_b + lane * 4);
 #pragma unroll
@@ -1675,8 +1685,22 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) bq[q] = ev_bload4(rB1, coff + (unsigned)((cA * 4 + wave) * 32 + 8 * q) * 4u, 0);
 
+            // Owner of a split tile, balanced build: the first contributor's partial tile is fetched UNDER the MFMAs of this pass's last
+            // chunk — flag word requested at the start of that chunk, published to the workgroup through the chunk's own two barriers,
+            // acquire by one lane between them, then eight sc1 loads per lane that land during phase 2.  (These loads sit under a
+            // wave-uniform branch, so hipcc drains vmcnt at the next use — once per split tile, in its last chunk only; issued
+            // unconditionally in every chunk they cost every chunk an L2 miss in front of its in-order fragment stream.)
+            const bool pf_ok = MODE == 0 && WPC == 2 && mp.sk.ctrl != nullptr && c0 == 0 && c1 < nchunk && cA == c0 && g + 1 < (int)gridDim.x;
+            bool pf_hit = false;
+            f32x4 PF[8];
             for (int hc = cA; hc < cB; ++hc) {
                 const int ht = hc * 4 + wave;                  // this wave's 32 hidden (MODE 1: output) channels of the chunk
+                const bool pf_try = pf_ok && hc == cB - 1;
+                unsigned pf_flag = 0;
+                if constexpr (MODE == 0 && WPC == 2) {
+                    const __amdgpu_buffer_rsrc_t rFl = ev_rsrc(mp.sk.flags ? (const void*)mp.sk.flags : (const void*)mp.b1);
+                    if (pf_try) pf_flag = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rFl, 0, (g + 1) * 4, 16);   // (scalar offset: one request per wave)
+                }
                 const int htn = hc + 1 < cB ? ht + 4 : cA * 4 + wave;   // next chunk's tile (after the last chunk: a harmless re-read)
                 // ================= phase 1: acc1 = W1[ht] . LN(x) + b1, K = 256 = 32 k-groups =================
                 f32x16 acc1;
@@ -1747,10 +1771,25 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
                     }
 #pragma unroll
                     for (int q = 0; q < 4; ++q) bq[q] = ev_bload4(rB1, coff + (unsigned)(htn * 32 + 8 * q) * 4u, 0);   // next chunk's bias, under phase 2
+                    if constexpr (WPC == 2) { if (pf_try && tid == 0) *skw = (pf_flag == tag) ? 1 : 0; }
                     ev_lds_barrier();        // every wave is done reading the previous chunk's Hs (its phase 2)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) *(f32x4*)(Hs + li * HLD + wave * 32 + 8 * q + 4 * lh) = hv[q];
+                    if constexpr (WPC == 2) {
+                        if (pf_try) {
+                            pf_hit = __builtin_amdgcn_readfirstlane(*skw) != 0;
+                            // (wave 0, a SCALAR branch: under `tid == 0` — a divergent branch inside the chunk loop — hipcc's uniformity analysis gave up on
+                            // the loop's offsets and wrapped every fragment load of both K loops in a waterfall loop)
+                            if (pf_hit && wave == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                        }
+                    }
                     ev_lds_barrier();
+                    if constexpr (WPC == 2) {
+                        if (pf_hit) {
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) PF[k] = ev_bload4_sc1(rPart, (unsigned)(g + 1) * pslot + pelem + (unsigned)k * 1024u);
+                        }
+                    }
                     // ================= phase 2: acc2 += W2[64 channels of this wave][chunk] . h, K = 128 = 16 k-groups =================
                     f32x4 B0 = *(const f32x4*)(hrow), B1;
                     auto mma2 = [&](const f32x4& a0, const f32x4& a1, const f32x4& b) {
@@ -1800,11 +1839,22 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
                             const f32x4 v = {acc2[a][0][4 * q], acc2[a][0][4 * q + 1], acc2[a][0][4 * q + 2], acc2[a][0][4 * q + 3]};
                             ev_bstore4_sc1(rPart, (unsigned)g * pslot + pelem + (unsigned)(a * 4 + q) * 1024u, v);
                         }
-                    sk_publish(mp.sk, g, tag, tid);
+                    pend_pub = true;
                     break;
                 }
                 // owner: add the contributors' partials in ascending workgroup order
                 bool again = false;
+                if constexpr (WPC == 2) {
+                    if (pf_hit && gi == g + 1) {           // the first contributor's tile is already in registers
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int e2 = 0; e2 < 4; ++e2) acc2[a][0][4 * q + e2] += PF[a * 4 + q][e2];
+                        ++gi;
+                    }
+                }
                 while (c1 < nchunk) {
                     const int s = sk_start(mp.sk, gi);
                     if (s >= tile_end) break;
@@ -1848,7 +1898,10 @@ __global__ __launch_bounds__(256, 3) void ln_mlp_kernel(const MlpParams mp) {
             }
         }
     }
-    if constexpr (MODE == 0) sk_arrive(mp.sk, tag, tid);
+    if constexpr (MODE == 0) {
+        if (pend_pub) sk_publish(mp.sk, g, tag, tid);   // (the partial was this workgroup's last segment)
+        sk_arrive(mp.sk, tag, tid);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1985,6 +2038,204 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnParams p) {
             *(f32x4*)(orow + 32 + 8 * g + 4 * lh) = c;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// attn_out_kernel: self-attention of BOTH heads + the output projection + the residual, one launch (round 3):
+//     H[q] += Wout . concat_h(softmax_k(q_h . k_h / 8 + m[k]) v_h) + bout          (transformer.py:262-271, diffusers Attention.to_out[0])
+// A workgroup is ONE 32-query tile of one utterance; its four waves are (head h, key half kh): wave (h, kh) runs the flash-style
+// loop of attention_kernel for head h over its half of the key tiles — on K / V tiles staged into LDS that is PRIVATE to the wave
+// (register-prefetched one tile ahead), so the key loop has no workgroup barrier at all — then the two key halves of a head are
+// merged through LDS (ascending order, deterministic), the normalised 32 x 128 output rows become the B operand of the
+// 128 -> 256 projection (each wave 64 output channels, weight fragments straight from L2 as in conv_gemm_kernel), and the lean
+// conv epilogue adds the residual rows and stores.  The additive mask rides in the QK product as one more MFMA (k-slot 0 = mask of
+// the key, times 1), so the softmax has no per-register LDS read.
+// Why this shape: at batch 64 the launches are about one round of workgroups; 128-query x one-head workgroups gave 640 / 384
+// workgroups of very unequal cost (T = 516 = 4 x 128 + 4: every fifth one held 4 queries) — 29-42 % MFMA-busy — followed by a
+// 128 -> 256 GEMM at 46-60 TFLOP/s.  32-query tiles are 1088 / 576 equal workgroups that the dispatcher deals out dynamically
+// (two resident per CU), and the projection runs on rows that never leave the CU.
+// ---------------------------------------------------------------------------
+struct AttnOutParams {
+    const float* QKV; int ld;   // rows: [q(2*64) | k(2*64) | v(2*64)]
+    const float* rowmask;
+    const float* Wout;          // fragment order [256/32][128/8][64 lanes][4]
+    ConvParams ep;              // epilogue view: Y = R = the hidden rows (in place), ldy = ldr, Cout = 256, bias, nrows / S / P / T
+    int S, P, T, B, nq;         // nq = ceil(T / 32) query tiles per utterance
+    float scale; int xcd_map;   // xcd_map: B % 8 == 0 -> the tiles of an utterance share an XCD (its K / V stay in that XCD's L2)
+};
+
+#define AO_LDK 68
+#define AO_OLD 132
+__global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int h = wave & 1, kh = wave >> 1;
+    int b, qt;
+    {
+        const int id = blockIdx.x;
+        if (p.xcd_map) { const int within = id >> 3; qt = within % p.nq; b = (id & 7) + 8 * (within / p.nq); }
+        else { b = id / p.nq; qt = id - b * p.nq; }
+    }
+    const int q0 = qt * 32;
+    const unsigned rowbase = (unsigned)b * p.S + p.P;
+    float* Ks = smem + wave * (2 * 32 * AO_LDK);       // this wave's private K tile [32 keys][64 + 4]
+    float* Vs = Ks + 32 * AO_LDK;                      // ... and V tile
+    const __amdgpu_buffer_rsrc_t rQ = ev_rsrc(p.QKV), rM = ev_rsrc(p.rowmask), rW = ev_rsrc(p.Wout);
+    const float L2E = 1.44269504088896340736f;
+    const unsigned ldb = (unsigned)p.ld * 4u;
+
+    // Q fragments: lane (query li, half lh) holds Q[q][8g + 4lh + s], pre-scaled into the log2 domain (exp(x) = exp2(x log2 e))
+    f32x4 qf[8];
+    {
+        const int tq = q0 + li;
+        const float qs = tq < p.T ? p.scale * L2E : 0.f;
+        const unsigned off = (rowbase + (unsigned)(tq < p.T ? tq : 0)) * ldb + (unsigned)(h * 64 + 4 * lh) * 4u;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) qf[g] = ev_bload4(rQ, off + (unsigned)(8 * g) * 4u, 0) * qs;
+    }
+    const int nkt = (p.T + 31) / 32, nh0 = (nkt + 1) / 2;
+    const int kt0 = kh ? nh0 : 0, kt1 = kh ? nkt : nh0;
+    // staging: float4 j of this lane = (key row 4j + lane/16, dims 4 (lane % 16) ..): a load instruction covers 4 rows x 256 B
+    f32x4 kr[8], vr[8];
+    float mk = 0.f;
+    const int srow = lane >> 4, sc4 = (lane & 15) * 4;
+    const unsigned kcol = (unsigned)(128 + h * 64 + sc4) * 4u, vcol = (unsigned)(256 + h * 64 + sc4) * 4u;
+    auto kv_issue = [&](int kt) {      // every load unconditional: keys beyond the utterance re-read its last frame and are masked out
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tk = kt * 32 + 4 * j + srow;
+            const unsigned ro = (rowbase + (unsigned)(tk < p.T ? tk : p.T - 1)) * ldb;
+            kr[j] = ev_bload4(rQ, ro + kcol, 0);
+            vr[j] = ev_bload4(rQ, ro + vcol, 0);
+        }
+        const int tm = kt * 32 + li;
+        const float m = ev_bload1(rM, (rowbase + (unsigned)(tm < p.T ? tm : p.T - 1)) * 4u, 0);
+        mk = tm < p.T ? m * L2E : -1e30f;
+    };
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float mrun = -1e30f, lrun = 0.f;
+    if (kt0 < kt1) kv_issue(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // publish the prefetched tile to this wave's LDS (the wave's LDS operations execute in order: no barrier, no other reader)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            *(f32x4*)(Ks + (4 * j + srow) * AO_LDK + sc4) = kr[j];
+            *(f32x4*)(Vs + (4 * j + srow) * AO_LDK + sc4) = vr[j];
+        }
+        const float amask = lh == 0 ? mk : 0.f;        // A operand of the mask product: k-slot 0 = mask of key li, k-slot 1 = 0
+        kv_issue(kt + 1 < kt1 ? kt + 1 : kt);          // next tile (after the last: a harmless re-read)
+        // S^T[key][q] = sum_d K[key][d] Q[q][d] + mask[key]
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 a = *(const f32x4*)(Ks + li * AO_LDK + 8 * g + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qf[g][e], s, 0, 0, 0);
+        }
+        s = __builtin_amdgcn_mfma_f32_32x32x2f32(amask, 1.0f, s, 0, 0, 0);
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - mnew); ps += s[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+        if (!__all(alpha == 1.0f)) {                   // (wave-uniform: the running maximum of most tiles after the first few is old)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        // O^T[d][q] += sum_key V[key][d] P^T[key][q]; register r pairs keys (kr, kr + 4) across the lane halves
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float a0 = Vs[key * AO_LDK + li];
+            const float a1 = Vs[key * AO_LDK + 32 + li];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, s[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], o1, 0, 0, 0);
+        }
+    }
+    // ---- first weight fragments of the projection (this wave: output channels 64 wave .. +63 = row tiles 2 wave, 2 wave + 1; 16
+    // k-groups), into the staging registers: they land while the key halves are merged
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto ldW = [&](int a, int kg) { return ev_bload4(rW, wlane, (unsigned)((wave * 2 + a) * 16 + kg) * 1024u); };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kr[j] = ldW(0, j); vr[j] = ldW(1, j); }
+    // ---- merge the two key halves of each head.  Wave (h, 1) leaves its state in its OWN (now dead) K / V region:
+    // [8 float4 slots of o0 | 8 of o1] x 64 lanes, then m and l; wave (h, 0) adds it to its own state (half 0 + half 1) and writes
+    // the normalised rows into Os[query][128] — inside wave 0's dead region (17.4 KB >= 16.9 KB)
+    float* Os = smem;                                  // [32][AO_OLD]
+    ev_lds_barrier();                                  // every wave has left its key loop
+    if (kh == 1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 a = {o0[4 * j], o0[4 * j + 1], o0[4 * j + 2], o0[4 * j + 3]};
+            const f32x4 c = {o1[4 * j], o1[4 * j + 1], o1[4 * j + 2], o1[4 * j + 3]};
+            *(f32x4*)(Ks + (j * 64 + lane) * 4) = a;
+            *(f32x4*)(Ks + ((4 + j) * 64 + lane) * 4) = c;
+        }
+        Ks[8 * 256 + lane] = mrun;
+        Ks[8 * 256 + 64 + lane] = lrun;
+    }
+    ev_lds_barrier();
+    if (kh == 0) {
+        const float* Ps = smem + (wave + 2) * (2 * 32 * AO_LDK);       // region of wave (h, 1)
+        const float m1 = Ps[8 * 256 + lane], l1 = Ps[8 * 256 + 64 + lane];
+        const float m = fmaxf(mrun, m1);
+        const float a0 = __builtin_amdgcn_exp2f(mrun - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+        const float inv = 1.0f / (lrun * a0 + l1 * a1);
+        const float w0 = a0 * inv, w1 = a1 * inv;
+        f32x4 oa[4], oc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 pa = *(const f32x4*)(Ps + (j * 64 + lane) * 4), pc = *(const f32x4*)(Ps + ((4 + j) * 64 + lane) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { oa[j][e] = o0[4 * j + e] * w0 + pa[e] * w1; oc[j][e] = o1[4 * j + e] * w0 + pc[e] * w1; }
+        }
+        // C/D register 4j + e of o0 is dim 8j + 4lh + e of query li (o1: + 32).  Os lies inside wave 0's region, dead since the
+        // barrier after the key loops, and the partner states are read from the regions of waves 2 / 3: no further barrier here
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *(f32x4*)(Os + li * AO_OLD + h * 64 + 8 * j + 4 * lh) = oa[j];
+            *(f32x4*)(Os + li * AO_OLD + h * 64 + 32 + 8 * j + 4 * lh) = oc[j];
+        }
+    }
+    ev_lds_barrier();
+    // ---- projection: Y^T[256][32] = Wout . O^T, K = 128 = 16 k-groups; bias preloaded into the accumulators (lean epilogue convention)
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (p.ep.bias) bq = *(const f32x4*)(p.ep.bias + wave * 64 + a * 32 + 8 * q + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][0][4 * q + e] = bq[e];
+        }
+    const float* orow = Os + li * AO_OLD + 4 * lh;
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) {
+        const f32x4 bfr = *(const f32x4*)(orow + kg * 8);
+        const f32x4 fa = kr[kg & 7], fb = vr[kg & 7];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], bfr[e], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[e], bfr[e], acc[1][0], 0, 0, 0);
+        }
+        if (kg < 8) { kr[kg] = ldW(0, kg + 8); vr[kg] = ldW(1, kg + 8); }
+    }
+    // ---- + residual rows, store (rows of THIS utterance only: a tile's tail rows may belong to the next one)
+    conv_epilogue_lean<2, 1, 1>(p.ep, acc, smem + wave * (32 * 68), wave * 64, (int)rowbase + q0, lane, (int)rowbase, (int)rowbase + p.T);
 }
 
 // ---------------------------------------------------------------------------

@@ -106,8 +106,12 @@ class Generator:
             self._dirty = False
 
     @torch.inference_mode()
-    def warmup(self, frames: int = 8) -> None:
-        """One tiny call: loads the code objects and allocates a first workspace (see MatchaTTS.warmup)."""
+    def warmup(self, frames: int = 8, max_frames: int = 0, batch: int = 1) -> None:
+        """One tiny call: loads the code objects and allocates a first workspace (see MatchaTTS.warmup).  ``max_frames``: pre-size
+        the workspace (and the denoiser's scratch) for utterances of up to that many mel frames through ``ev_reserve``."""
+        self._sync_engine()
+        if max_frames > 0:
+            self.engine.reserve(batch, 0, 0, max_frames)
         self.forward(torch.zeros((1, 80, frames), dtype=torch.float32, device=self.device))
         torch.cuda.synchronize(self.device)
 

@@ -6,9 +6,12 @@ Keeps the reference call surface (matcha_tts.py:78, return keys :145-152):
 
 ``.n_spks``, ``.eval()``, ``.to(device)`` and ``MatchaTTS.load_from_checkpoint(path,
 map_location=)`` behave as the callers in cli.py / feel_me.py expect.  The text
-encoder, duration maths and alignment run as plain torch ops (host stage); the CFM
-Euler loop over the U-Net estimator runs in the HIP library through the C ABI
-(``ev_cfm_decode``).  Training (``forward``) is out of scope and raises.
+encoder + duration predictor (``ev_text_encoder``), the monotonic alignment
+(``ev_align``) and the CFM Euler loop over the U-Net estimator (``ev_cfm_decode2``)
+run in the HIP library through the C ABI; only the duration rounding and the
+integer ``y_lengths`` stay torch ops (data-dependent sizes, matcha_tts.py:121-128).
+``encoder_stage = "host"`` selects the plain-torch text encoder + alignment instead
+(north_star's "run once on host").  Training (``forward``) is out of scope and raises.
 """
 from __future__ import annotations
 
@@ -175,9 +178,14 @@ class MatchaTTS:
         }
 
     @torch.inference_mode()
-    def warmup(self, n_tokens: int = 16, n_timesteps: int = 2) -> None:
+    def warmup(self, n_tokens: int = 16, n_timesteps: int = 2, max_frames: int = 0, max_tokens: int = 0, batch: int = 1) -> None:
         """One tiny synthesis so that the first real request does not pay for code-object loading and the first workspace
-        allocation (150-400 ms on a fresh process).  No reference counterpart."""
+        allocation (150-400 ms on a fresh process).  ``max_frames`` (mel frames of the longest utterance to expect; ``max_tokens``
+        likewise for the text, default ``max_frames``) pre-sizes the workspace, scratch and staging through ``ev_reserve``, so
+        that no later request up to that length allocates or re-plans on the request path.  No reference counterpart (torch's
+        caching allocator amortises the same cost, feel_me.py:181-203)."""
+        if max_frames > 0:
+            self.engine.reserve(batch, max_tokens if max_tokens > 0 else max_frames, fix_len_compatibility(max_frames), 0)
         ids = torch.ones((1, n_tokens), dtype=torch.long, device=self.device)
         lens = torch.tensor([n_tokens], device=self.device)
         spks = torch.zeros((1,), dtype=torch.long, device=self.device) if self.n_spks > 1 else None
@@ -200,9 +208,7 @@ class MatchaTTS:
             z = self.draw_noise(B, Tp)
         x0 = (z.to(self.device) * temperature).contiguous()
         mu_c = mu_y.contiguous()
-        dec = self.engine.cfm_decode(mu_c, y_lengths, spk, x0, n_timesteps)
-        mel = dec * self.mel_std + self.mel_mean
-        return dec, mel
+        return self.engine.cfm_decode2(mu_c, y_lengths, spk, x0, n_timesteps, self.mel_std, self.mel_mean)
 
 
 # ---------------------------------------------------------------------------

@@ -27,8 +27,25 @@ class BatchPipeline:
         self.last_event = None
         # the vocoder stays on ONE stream here: its small-call fan-out over three streams first drains the caller's stream on
         # the host (emojivoice.h, ev_hifigan), which would stall this pipeline's enqueue-ahead; the decode stream fills the gaps
+        # The limit is the handle's: a vocoder that also serves single requests (EmojiTTS, to_waveform) gets its fan-out back
+        # from close() / the context-manager exit.
         vocoder._sync_engine()
+        self._mrf_restore = vocoder.engine.mrf_streams_max
         vocoder.engine.set_mrf_streams_max(0)
+
+    def close(self) -> None:
+        """Drain both streams and give the vocoder engine its small-call three-stream fan-out limit back."""
+        self.synchronize()
+        if self._mrf_restore is not None and self.vocoder.engine is not None:
+            self.vocoder.engine.set_mrf_streams_max(self._mrf_restore)
+            self._mrf_restore = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
 
     def submit(self, mu, lengths, spk, z, n_timesteps: int, return_mel: bool = False):
         """mu / z: (B, n_feats, Tp) normalised encoder output and temperature-scaled noise (flow_matching.py:32-50),
@@ -76,3 +93,14 @@ class PipelineGroup:
     def synchronize(self) -> None:
         for p in self.pipes:
             p.synchronize()
+
+    def close(self) -> None:
+        for p in self.pipes:
+            p.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

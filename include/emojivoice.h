@@ -23,9 +23,15 @@
  *     caller (PyTorch-ROCm in the shipped host layer); they are borrowed for the
  *     duration of the call and all work is enqueued asynchronously on `stream`
  *     (a hipStream_t passed as void*; NULL = the default stream).
- *   - The handle owns the re-laid-out weights and a workspace that grows on demand
- *     (growth = hipMalloc, so the first call at a new (B,T) is not graph-capturable; later ev_cfm_decode calls at that shape
- *     are: they enqueue kernels and one pinned-memory copy and never wait on the host — tests/test_gpu_configs.py).
+ *   - The handle owns the re-laid-out weights and a workspace that grows on demand, geometrically (growth = a wait for the
+ *     handle's streams + hipFree + hipMalloc).  ev_reserve sizes everything once, up front, so that no later call at or below
+ *     the reserved shape allocates or waits (a streaming server reserves its longest utterance: ev_alloc_count stays put).
+ *   - Graph capture: the first call at a new (B, Tp) plans and zeroes the workspace and is not capturable; later ev_cfm_decode
+ *     calls at that shape are (they enqueue kernels and one pinned-memory copy and never wait on the host).  A captured call
+ *     stages its per-step time embeddings in pinned memory that the handle never reuses, and BINDS the handle to its (B, Tp):
+ *     afterwards ev_cfm_decode at another shape, a growth of the workspace, or more Euler steps than the workspace is planned for
+ *     (64, or the largest n_steps of an earlier call) return an error instead of pulling memory from under the graph; eager calls
+ *     at the captured shape with any admissible n_steps are fine.  At most 8 captured calls per handle.
  *   - Layout at the boundary is the reference's: mel-like tensors are (B, 80, T)
  *     channel-major contiguous; waveforms are (B, 256*T) contiguous.
  *   - Every function returns 0 on success, non-zero on failure; the message is
@@ -43,7 +49,7 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 1
+#define EV_ABI_VERSION 2
 
 typedef struct ev_handle ev_handle;
 
@@ -91,6 +97,21 @@ size_t ev_workspace_bytes(ev_handle *h, int B, int Tp_cfm, int T_voc);
  *   Tp must be a multiple of 4 (fix_len_compatibility, utils/model.py:14-20). */
 int ev_cfm_decode(ev_handle *h, const float *d_mu, const int32_t *d_lengths, const float *d_spk, const float *d_z,
                   int B, int Tp, int n_steps, float out_scale, float out_shift, float *d_out, void *stream);
+
+/* The same decode with both of the reference's outputs (matcha_tts.py:139-152): d_dec = "decoder_outputs" (may be NULL),
+ * d_mel = "mel" = denormalize(decoder_outputs, mel_mean, mel_std) = dec * mel_std + mel_mean (may be NULL; not both). */
+int ev_cfm_decode2(ev_handle *h, const float *d_mu, const int32_t *d_lengths, const float *d_spk, const float *d_z,
+                   int B, int Tp, int n_steps, float *d_dec, float mel_std, float mel_mean, float *d_mel, void *stream);
+
+/* Pre-size everything the hot calls allocate on demand, for batches of B utterances of up to Tx_max tokens (ev_text_encoder),
+ * Tp_max mel frames (ev_cfm_decode / ev_estimator; multiple of 4) and T_voc_max mel frames (ev_hifigan, ev_denoise at
+ * L = 256 * T_voc_max): the workspace arena, the text-encoder and denoiser scratch, the pinned time-embedding ring, the
+ * denoiser's DFT bases and the side streams of the small-call vocoder.  0 skips a stage.  After it, calls with the same B and
+ * lengths up to the reserved ones never allocate (ev_alloc_count does not move) and never wait for the device to re-plan.
+ * The reference has no counterpart: torch's caching allocator amortises the same cost (feel_me.py:181-203). */
+int ev_reserve(ev_handle *h, int B, int Tx_max, int Tp_max, int T_voc_max, void *stream);
+/* Device / pinned allocations made by the hot calls since ev_create (workspace growth, scratch growth, staging). */
+int64_t ev_alloc_count(ev_handle *h);
 
 /* One estimator evaluation v = Decoder(x, mask, mu, t, spk)  (decoder.py:363-443). */
 int ev_estimator(ev_handle *h, const float *d_x, const float *d_mu, const int32_t *d_lengths, const float *d_spk,
@@ -150,6 +171,10 @@ int ev_profile_read(ev_handle *h, double *conv_ms, double *conv_flops, int64_t *
  * dbg = ablation bits, cfg = forced tile configuration (< 0: the engine's own choice). */
 int ev_dbg_conv_bench(ev_handle *h, int Cin, int Cout, int K, int dil, int B, int T, int P, int iters, int dbg, int cfg, float *ms_out);
 
+/* Diagnostic: the control words of the balanced ("stream-K") launches (ev_kernels.h, SkCtl) after a device synchronisation:
+ * out3 = {launches so far (epoch), arrivals of an unfinished launch (0), hand-off waits that ran out and were recomputed}. */
+int ev_dbg_sk_stats(ev_handle *h, uint32_t *out3);
+
 /* ---- operator-level entry points (unit parity tests call these) ------------------
  * Activations here are frame-major (rows, C) fp32 with an explicit row stride. */
 int ev_op_conv1d(ev_handle *h, const float *d_x /*(B,Cin,T)*/, const float *w /*HOST (Cout,Cin,K)*/,
@@ -167,6 +192,11 @@ int ev_op_ln_mlp(ev_handle *h, const float *d_x, const float *d_ln_g, const floa
                  int rows, int M1, int mode, float *d_y, void *stream);
 int ev_op_attention(ev_handle *h, const float *d_qkv /*(B,T,3*heads*64)*/, const int32_t *d_lengths, int B, int T,
                     int heads, float *d_out /*(B,T,heads*64)*/, void *stream);
+
+/* attn_out_kernel: d_hid (B*T, 256) <- d_hid + Wout . Attention(d_qkv) + bout, both heads, additive float mask (transformer.py:262-271);
+ * d_qkv (B, T, 384) = [q | k | v] x (2 heads x 64); w_out (256, 128) and b_out (256) are HOST pointers. */
+int ev_op_attn_out(ev_handle *h, const float *d_qkv, const int32_t *d_lengths, int B, int T, const float *w_out, const float *b_out,
+                   float *d_hid, void *stream);
 
 #ifdef __cplusplus
 }

@@ -155,27 +155,38 @@ def _synth_body(rank, world, port, q):
     vocoder = lambda mel: O.hifigan_forward(voc_sd, mel, W.HIFIGAN_V1)   # noqa: E731
     torch.manual_seed(4242)                                    # same seed on every rank -> the same GLOBAL draw
     out = D.synthesise_sharded(model, vocoder, ids, xl, 2, 0.667, spks, 1.0)
-    # single-process reference run of the whole batch with the same seed (the oracle's own synthesise)
+    # single-process reference run of the whole batch with the same seed (the oracle's own synthesise) and the vocoder on ITS mel
     torch.manual_seed(4242)
     ref = O.synthesise(sd, ids, xl, 2, 0.667, spks, 1.0)
     Tp = O.fix_len_compatibility(int(ref["mel_lengths"].max()))
     lo, hi = out["rows"]
-    n = ref["mel"].shape[-1]                                   # the single-process run trims to max(y_lengths); the sharded one keeps Tp
-    e_mel = float((out["mel"][:, :, :n] - ref["mel"][lo:hi]).abs().max())
-    # the sharded run vocodes the untrimmed Tp-frame mel: build the same thing for the whole batch in one process
-    torch.manual_seed(4242)
-    _, _, mel_tp, _ = model._decode_aligned(*model._durations(ids, xl, spks, 1.0)[:6], Tp, 2, 0.667, z=model.draw_noise(B, Tp))
-    ref_wav = O.hifigan_forward(voc_sd, mel_tp, W.HIFIGAN_V1).clamp(-1, 1)
-    e_wav = float((out["wav"] - ref_wav).abs().max())
+    e_mel = float((out["mel"] - ref["mel"][lo:hi]).abs().max()) if out["mel"].shape == ref["mel"][lo:hi].shape else 1e9
+    ref_wav = O.hifigan_forward(voc_sd, ref["mel"], W.HIFIGAN_V1).clamp(-1, 1)          # = to_waveform(synthesise(...)["mel"])
+    e_wav = float((out["wav"] - ref_wav).abs().max()) if out["wav"].shape == ref_wav.shape else 1e9
     same_len = bool(torch.equal(out["mel_lengths"], ref["mel_lengths"]))
-    q.put((rank, out["Tp"], Tp, tuple(out["wav"].shape), e_mel, e_wav, same_len, out["ranks"]))
+    # a token id outside the embedding table in ONE shard (rank 1's rows) must raise IndexError on EVERY rank, not hang the others
+    bad = ids.clone()
+    bad[4, 2] = 100000
+    try:
+        D.synthesise_sharded(model, vocoder, bad, xl, 2, 0.667, spks, 1.0)
+        collective_error = "no error"
+    except IndexError:
+        collective_error = "IndexError"
+    try:                                                       # fewer utterances than ranks: every rank refuses before any collective
+        D.synthesise_sharded(model, vocoder, ids[:1], xl[:1], 2, 0.667, spks[:1], 1.0)
+        small = "no error"
+    except ValueError:
+        small = "ValueError"
+    q.put((rank, out["Tp"], Tp, tuple(out["wav"].shape), int(ref["mel_lengths"].max()), e_mel, e_wav, same_len, out["ranks"], collective_error, small))
     D.barrier()
     dist.destroy_process_group()
 
 
 def test_synthesise_sharded_equals_single_process():
-    for rank, tp, want_tp, shape, e_mel, e_wav, same_len, ranks in _spawn(_worker_synth, timeout=600):
+    for rank, tp, want_tp, shape, y_max, e_mel, e_wav, same_len, ranks, collective_error, small in _spawn(_worker_synth, timeout=600):
         assert ranks == 2 and tp == want_tp
-        assert shape == (5, 1, 256 * tp)
+        assert shape == (5, 1, 256 * y_max)                    # the vocoder saw the mel trimmed to max(y_lengths), as synthesise returns it
         assert same_len                                        # mel_lengths ride along in the one gather, exact
         assert e_mel <= 1e-5 and e_wav <= 1e-5, (rank, e_mel, e_wav)
+        assert collective_error == "IndexError", (rank, collective_error)   # raised on BOTH ranks (the bad id sits in rank 1's shard)
+        assert small == "ValueError"

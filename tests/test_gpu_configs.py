@@ -177,27 +177,38 @@ def test_config5_streaming_loop_vs_oracle(model, vocoder, sds):
 # ---------------------------------------------------------------------------------------------------------------------
 # durations: the device text encoder must give the host stage's integer mel lengths
 # ---------------------------------------------------------------------------------------------------------------------
-def test_device_encoder_duration_flips(model):
-    """``mel_lengths`` are integers (ceil of exp(logw)): bit-exact is the bar.  Count, over 200 random id sequences, how
-    often the device text encoder (ev_text_encoder) and the plain-torch host stage disagree on any token's ceil()."""
+def test_device_encoder_duration_flips(model, sds):
+    """``mel_lengths`` are integers (``ceil(exp(logw))`` summed and truncated, matcha_tts.py:122-124): bit-exact against the CPU
+    reference is the bar.  Over 200 random id sequences the device text encoder (``ev_text_encoder``) is compared with the CPU
+    oracle's text encoder: per-token ``ceil()`` and, through the product's own ``_durations``, the integer ``mel_lengths`` at
+    length scales 1.0 and 0.8.  A flip needs ``exp(logw)`` within ~1e-6 (relative) of an integer; the count is printed and must be 0."""
     g = torch.Generator().manual_seed(2024)
-    flips = tokens = 0
-    worst = 0.0
+    flips = tokens = len_flips = 0
+    worst, nearest = 0.0, 1.0
     for _ in range(20):
         B, Tx = 10, 48
-        ids = torch.randint(1, 178, (B, Tx), generator=g).cuda()
-        xl = torch.randint(8, Tx + 1, (B,), generator=g).cuda()
-        sid = torch.randint(0, 109, (B,), generator=g).cuda()
-        spk = model._sd["spk_emb.weight"][sid]
-        mu_d, logw_d = model.engine.text_encoder(ids, xl, spk)
-        mu_h, logw_h, x_mask = model.encoder(ids, xl, spk)
-        wd, wh = torch.ceil(torch.exp(logw_d) * x_mask), torch.ceil(torch.exp(logw_h) * x_mask)
-        flips += int((wd != wh).sum())
+        ids = torch.randint(1, 178, (B, Tx), generator=g)
+        xl = torch.randint(8, Tx + 1, (B,), generator=g)
+        sid = torch.randint(0, 109, (B,), generator=g)
+        spk_c = sds[0]["spk_emb.weight"][sid]
+        with torch.inference_mode():
+            mu_o, logw_o, x_mask = O.text_encoder(sds[0], ids, xl, spk_c)                  # CPU oracle
+        mu_d, logw_d = model.engine.text_encoder(ids.cuda(), xl.cuda(), spk_c.cuda())
+        w_o = torch.exp(logw_o) * x_mask
+        wd, wo = torch.ceil(torch.exp(logw_d.cpu()) * x_mask), torch.ceil(w_o)
+        flips += int((wd != wo).sum())
         tokens += int(x_mask.sum())
-        worst = max(worst, float(((logw_d - logw_h) * x_mask).abs().max()))
-    print(f"duration flips: {flips} of {tokens} tokens over 200 sequences; worst |dlogw| {worst:.2e}")
+        worst = max(worst, float(((logw_d.cpu() - logw_o) * x_mask).abs().max()))
+        frac = (w_o - torch.floor(w_o))[x_mask.bool()]
+        nearest = min(nearest, float(torch.minimum(frac, 1 - frac).min()))
+        for scale in (1.0, 0.8):
+            y_o = torch.clamp_min(torch.sum(wo * scale, [1, 2]), 1).long()
+            y_d = model._durations(ids, xl, sid, scale)[5].cpu()
+            len_flips += int((y_o != y_d).sum())
+    print(f"duration flips vs the CPU oracle: {flips} of {tokens} tokens, {len_flips} of 400 mel_lengths over 200 sequences; "
+          f"worst |dlogw| {worst:.2e}; nearest exp(logw) to an integer {nearest:.2e}")
     assert worst <= 1e-4
-    assert flips <= 2, (flips, tokens)      # a flip needs exp(logw) within ~1e-6 of an integer
+    assert flips == 0 and len_flips == 0, (flips, tokens, len_flips)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -355,9 +366,51 @@ def test_synthesise_sharded_single_rank_equals_synthesise(model, vocoder):
     torch.manual_seed(5)
     ref = model.synthesise(ids, xl, 3, 0.667, spks, 0.8)
     assert torch.equal(out["mel_lengths"].cpu(), ref["mel_lengths"].cpu()) and out["ranks"] == 1
-    n = ref["mel"].shape[-1]
-    assert torch.equal(out["mel"][:, :, :n], ref["mel"])
-    assert out["wav"].shape == (3, 1, 256 * out["Tp"]) and bool(torch.isfinite(out["wav"]).all())
+    assert torch.equal(out["mel"], ref["mel"])                # trimmed to max(y_lengths), as synthesise returns it
+    assert out["y_max"] == int(ref["mel_lengths"].max()) and out["Tp"] == (out["y_max"] + 3) // 4 * 4
+    assert torch.equal(out["wav"], vocoder(ref["mel"]).clamp(-1, 1))     # = to_waveform(synthesise(...)["mel"])
+
+
+def test_sharded_two_rank_semantics_on_one_gpu(model, vocoder, sds):
+    """The N > 1 path with the REAL engine, world size 2 emulated on one GPU: a ragged batch of 5 is computed as
+    rank 0's rows and rank 1's rows, one after the other, through ``dist.shard_durations`` / ``shard_decode`` — each at the
+    GLOBAL padded length and on its rows of ONE global noise draw, which is where the padding-coupled numerics bite (GroupNorm
+    statistics and attention see padded frames, decoder.py:41-43) — and concatenated the way ``all_gather_rows`` collates the
+    blocks.  The result must equal the single-batch run on the same engine and pass the oracle gates."""
+    from emojivoice_amd import dist as D
+
+    sd, voc_sd = sds
+    g = torch.Generator().manual_seed(314)
+    B, Lx = 5, 30
+    ids = torch.randint(1, 178, (B, Lx), generator=g)
+    xl = torch.tensor([30, 11, 24, 7, 19])                     # rank 1's rows are all shorter than rank 0's longest
+    spks = torch.tensor([107, 58, 0, 12, 17])
+    with torch.inference_mode():
+        probe = O.synthesise(sd, ids, xl, 2, 0.667, spks, 1.0, z=None)
+    y_max = int(probe["mel_lengths"].max())
+    Tp = O.fix_len_compatibility(y_max)
+    z = torch.randn(B, 80, Tp, generator=g)
+    with torch.inference_mode():
+        ref = O.synthesise(sd, ids, xl, 4, 0.667, spks, 1.0, z=z)
+        ref_wav = O.hifigan_forward(voc_sd, ref["mel"], W.HIFIGAN_V1).clamp(-1, 1)
+    # single batch on the engine
+    one = model.synthesise(ids.cuda(), xl.cuda(), 4, 0.667, spks.cuda(), 1.0, z=z.cuda())
+    one_wav = vocoder(one["mel"]).clamp(-1, 1)
+    # two ranks, sequentially
+    states = [D.shard_durations(model, ids.cuda(), xl.cuda(), spks.cuda(), 1.0, r, 2) for r in range(2)]
+    assert [(s.lo, s.hi) for s in states] == [(0, 3), (3, 5)] and all(s.error is None for s in states)
+    y_max_g = max(s.y_max_local for s in states)               # what agree_max_length's MAX all-reduce returns
+    assert y_max_g == y_max and states[1].y_max_local < y_max  # rank 1 alone would have padded to a shorter Tp
+    blocks, mels = zip(*[D.shard_decode(model, vocoder, s, y_max_g, z.cuda(), 4, 0.667) for s in states])
+    full = torch.cat(blocks, dim=0)                            # all_gather_rows: blocks in rank order (equal-row padding dropped)
+    out = D.collate_blocks(full, Tp, y_max_g, 0, 3, 2, mels[0])
+    assert torch.equal(out["mel_lengths"].cpu(), ref["mel_lengths"])
+    mel2 = torch.cat(mels, dim=0)
+    # (i) the sharded computation equals the single batch on the same engine (tile configurations may differ with the batch size)
+    assert _linf(mel2, one["mel"].cpu()) <= 1e-5 and _linf(out["wav"], one_wav.cpu()) <= 5e-5
+    # (ii) the oracle gates
+    assert _linf(mel2, ref["mel"]) <= MEL_GATE and _rms(out["wav"], ref_wav) <= WAV_RMS_GATE
+    assert out["wav"].shape == (B, 1, 256 * y_max)
 
 
 def test_rccl_backend_single_rank_collectives():
@@ -412,9 +465,15 @@ def test_geometry_changes_leave_no_stale_rows(model, vocoder):
                 first[(B, T)] = out
 
 
-def test_cfm_decode_is_stream_capturable(model):
+def test_cfm_decode_is_stream_capturable(sds):
     """ev_cfm_decode enqueues only kernels and one pinned-memory copy on the caller's stream (no host wait under capture), so a
-    serving loop may capture a decode of a fixed (B, Tp) in a HIP graph; the replay reproduces the direct call bit for bit."""
+    serving loop may capture a decode of a fixed (B, Tp) in a HIP graph; the replay reproduces the direct call bit for bit — also
+    after eager calls with OTHER step counts on the same handle (the captured call's time embeddings sit in pinned memory the
+    handle never reuses), and the handle refuses what would pull memory from under the graph (another shape)."""
+    from emojivoice_amd._lib import EvLibraryError
+    from emojivoice_amd.matcha_tts import MatchaTTS
+
+    model = MatchaTTS(sds[0], device=DEV)                    # its own handle: a captured call binds the handle to its shape
     dev = model.device
     g = torch.Generator().manual_seed(11)
     B, T = 1, 60
@@ -432,4 +491,69 @@ def test_cfm_decode_is_stream_capturable(model):
         out.zero_()
         graph.replay()
         torch.cuda.synchronize(dev)
-    assert torch.equal(out, ref)
+        assert torch.equal(out, ref)
+        # eager calls with other step counts (other time grids in the handle's staging ring, twice: both ring slots) ...
+        ref5 = model.engine.cfm_decode(mu, lengths, spk, z, 5)
+        ref7 = model.engine.cfm_decode(mu, lengths, spk, z, 7)
+        assert not torch.equal(ref5, ref) and not torch.equal(ref7, ref5)
+        out.zero_()
+        graph.replay()                                        # ... must not change what the graph computes
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out, ref)
+        with pytest.raises(EvLibraryError, match="captured"):   # another shape would re-plan the workspace under the graph
+            model.engine.cfm_decode(mu[:, :, :40].contiguous(), torch.tensor([40], device=dev), spk, z[:, :, :40].contiguous(), 3)
+        with pytest.raises(EvLibraryError, match="captured"):   # more Euler steps than the workspace is planned for
+            model.engine.cfm_decode(mu, lengths, spk, z, 100)
+        out.zero_()
+        graph.replay()
+        torch.cuda.synchronize(dev)
+        assert torch.equal(out, ref)
+    model.engine.close()
+
+
+def test_reserved_handles_do_not_allocate_on_the_request_path(sds):
+    """``MatchaTTS.warmup(max_frames=)`` / ``Generator.warmup(max_frames=)`` (ev_reserve) size the workspace, the text-encoder and
+    denoiser scratch, the pinned staging ring and the vocoder's side streams once: 20 requests of lengths never seen before (all
+    within the reservation) must not move ``ev_alloc_count``, and must still be right (one compared with an unreserved handle).
+    Unreserved handles grow geometrically: far fewer allocations than new maxima."""
+    from emojivoice_amd import streaming as S
+    from emojivoice_amd.denoiser import Denoiser
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+    from emojivoice_amd.matcha_tts import MatchaTTS
+
+    def pair():
+        m = MatchaTTS(sds[0], device=DEV)
+        v = Generator(AttrDict(v1)).to(DEV)
+        v.load_state_dict(sds[1])
+        return m, v
+
+    m, v = pair()
+    m.rng = "device"
+    den = Denoiser(v, mode="zeros")
+    m.warmup(max_frames=1000, max_tokens=700)
+    v.warmup(max_frames=1000)
+    tts = S.EmojiTTS(m, v, den, text_to_ids=S.table_front_end)
+    tts.respond("warm up \U0001F642")
+    torch.cuda.synchronize()
+    a_m, a_v = m.engine.alloc_count(), v.engine.alloc_count()
+    words = "the quick brown fox jumps over the lazy dog and runs far away from here ".split()
+    lens = set()
+    for i in range(20):
+        txt = " ".join(words[(i * 3 + k) % len(words)] for k in range(3 + 2 * i))
+        out = tts.respond(txt + " \U0001F60D")
+        lens.add(int(out["mel_lengths"][0]))
+        assert bool(torch.isfinite(out["waveform"]).all())
+    torch.cuda.synchronize()
+    assert len(lens) >= 15 and max(lens) <= 1000
+    assert (m.engine.alloc_count(), v.engine.alloc_count()) == (a_m, a_v), "a reserved handle allocated on the request path"
+    # the same increasing lengths on fresh, unreserved handles: geometric growth, not one allocation per new maximum
+    m2, v2 = pair()
+    m2.rng = "device"
+    tts2 = S.EmojiTTS(m2, v2, Denoiser(v2, mode="zeros"), text_to_ids=S.table_front_end)
+    for i in range(20):
+        txt = " ".join(words[(i * 3 + k) % len(words)] for k in range(3 + 2 * i))
+        tts2.respond(txt + " \U0001F60D")
+    torch.cuda.synchronize()
+    assert 0 < m2.engine.alloc_count() <= 16 and 0 < v2.engine.alloc_count() <= 16, (m2.engine.alloc_count(), v2.engine.alloc_count())
+    for o in (m, v, m2, v2):
+        o.engine.close()

@@ -114,6 +114,28 @@ def test_attention(eng, B, T, lens):
     _close(got, ref, rtol=2e-5, what="attention")
 
 
+@pytest.mark.parametrize("B,T,lens", [(3, 70, [70, 33, 1]), (2, 516, [516, 400]), (8, 258, [258, 1, 100, 258, 31, 32, 33, 257]), (1, 32, [32]),
+                                      (2, 4, [4, 2]), (64, 132, None)])
+def test_attn_out_fused(eng, B, T, lens):
+    """attn_out_kernel (both heads of the additive-mask attention + the 128 -> 256 output projection + the residual in one launch,
+    transformer.py:262-271) against plain torch fp32 (SDPA with the FLOAT mask added, then Linear with bias, then + hidden)."""
+    g = torch.Generator().manual_seed(T * 7 + B)
+    heads = 2
+    qkv = torch.randn(B, T, 3 * heads * 64, generator=g)
+    hid = torch.randn(B, T, 256, generator=g)
+    w_out = torch.randn(256, 128, generator=g) / 128 ** 0.5
+    b_out = torch.randn(256, generator=g) * 0.1
+    lengths = torch.tensor(lens) if lens is not None else torch.randint(1, T + 1, (B,), generator=g)
+    mask = (torch.arange(T)[None] < lengths[:, None]).float()
+    q, k, v = (qkv[..., i * 128:(i + 1) * 128].view(B, T, heads, 64).transpose(1, 2) for i in range(3))
+    am = mask.repeat_interleave(heads, dim=0).view(B, heads, 1, T)     # FLOAT mask: added to the scores
+    att = F.scaled_dot_product_attention(q, k, v, attn_mask=am).transpose(1, 2).reshape(B, T, heads * 64)
+    ref = hid + att @ w_out.T + b_out
+    got = eng.op_attn_out(qkv.cuda(), lengths.cuda(), w_out, b_out, hid.cuda())
+    _close(got, ref, rtol=2e-5, what="attention + out-proj + residual")
+    assert torch.equal(eng.op_attn_out(qkv.cuda(), lengths.cuda(), w_out, b_out, hid.cuda()), got)      # deterministic
+
+
 @pytest.mark.parametrize("rows,M1", [(70, 1024), (1, 1024), (333, 384), (32, 128)])
 def test_ln_mlp_fused(eng, rows, M1):
     """ln_mlp_kernel (LayerNorm + feed-forward / LayerNorm + projection in one launch) against plain torch fp32:

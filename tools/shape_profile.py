@@ -31,11 +31,14 @@ lengths = torch.full((B,), T, dtype=torch.int32).to(dev)
 spk = m._sd["spk_emb.weight"][torch.arange(B, device=dev) % 109]
 for it in range(2):
     if it == 1:
+        voc._sync_engine()
         voc.engine.profile_enable(True)
         m.engine.profile_enable(True)
-    wav = voc(mel)
+    if not os.environ.get("EV_SP_NOVOC"):
+        wav = voc(mel)
     dec = m.engine.cfm_decode(mu, lengths, spk, z, 10)
     torch.cuda.synchronize()
 print("hifigan", voc.engine.profile_read())
 print("cfm", m.engine.profile_read())
+print("sk_stats (launches, arrivals, timed-out waits)", m.engine.sk_stats())
 print(open(out).read())
