@@ -281,6 +281,92 @@ def run_config5(args, device):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# compact config-4 / config-5 records for the default line (so that the driver's own run carries them)
+# ---------------------------------------------------------------------------------------------------------------------
+def config4_record(sd, model, mu, z, spk, lengths, T):
+    """ODE-step sweep at the bench batch (flow_matching.py:55-85): CFM decode ms at n in {2, 4, 10, 20, 50}, mel-MSE against the
+    n = 50 output, and mel L-inf of ROW 0 against the CPU oracle at the same n."""
+    from oracle import matcha_oracle as O
+
+    outs, ms = {}, {}
+    for n in (50, 2, 4, 10, 20):
+        model.engine.cfm_decode(mu, lengths, spk, z, n)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            outs[n] = model.engine.cfm_decode(mu, lengths, spk, z, n)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ms[n] = sorted(ts)[1]
+    torch.set_num_threads(host_cores())
+    rec = {"batch": int(mu.shape[0]), "frames": T, "cpu_row": 0, "sweep": []}
+    for n in (2, 4, 10, 20, 50):
+        with torch.inference_mode():
+            ref = O.solve_euler(sd, z[:1].cpu(), mu[:1].cpu(), torch.ones(1, 1, T), n, spk[:1].cpu())
+        rec["sweep"].append({"ode_steps": n, "cfm_ms": round(ms[n], 2), "mel_mse_vs_50": float(((outs[n] - outs[50]) ** 2).mean()),
+                             "mel_linf_vs_cpu_same_n": float((outs[n][:1].cpu() - ref).abs().max())})
+    return rec
+
+
+def config5_record(model, voc, n_utt=32):
+    """feel_me.py TTS loop (feel_me.py:189-203) at B = 1, text on the host -> denoised waveform on the host, twice over n_utt
+    mixed-length utterances on handles reserved for 10-s utterances (ev_reserve):
+      warm: every text was synthesised once before the timed loop (its length has been planned before);
+      cold: texts, hence mel lengths, that this process has never synthesised (each request re-plans the workspace for a new
+            length: pad-row zeroing, no allocation — `allocs_during` counts them)."""
+    import numpy as np
+
+    from emojivoice_amd import streaming as S
+    from emojivoice_amd.denoiser import Denoiser
+    from emojivoice_amd.emoji import EMOJI_MAPPING
+
+    rng_was = model.rng
+    model.rng = "device"           # the reference draws the prior on the device it runs on (flow_matching.py:51)
+    den = Denoiser(voc, mode="zeros")
+    model.warmup(max_frames=1000, max_tokens=1000)
+    voc.warmup(max_frames=1000)
+    tts = S.EmojiTTS(model, voc, den, text_to_ids=S.table_front_end)
+    emojis = list(EMOJI_MAPPING.keys()) + ["\U0001F60A"]
+    g = torch.Generator().manual_seed(4321)
+
+    def make_text(n_chars, gen):
+        words, n = [], 0
+        while n < n_chars:
+            w = _WORDS[int(torch.randint(0, len(_WORDS), (1,), generator=gen))]
+            words.append(w)
+            n += len(w) + 1
+        return " ".join(words)[:n_chars]
+
+    def run(texts):
+        lat, frames = [], []
+        for i, t in enumerate(texts):
+            t0 = time.perf_counter()
+            out = tts.respond(t + " " + emojis[i % len(emojis)])
+            lat.append(time.perf_counter() - t0)
+            frames.append(int(out["mel_lengths"][0]))
+        lat = np.array(lat) * 1e3
+        return {"p50_ms": round(float(np.percentile(lat, 50)), 2), "p99_ms": round(float(np.percentile(lat, 99)), 2),
+                "mean_ms": round(float(lat.mean()), 2), "mean_frames": round(float(np.mean(frames)), 1),
+                "min_frames": int(min(frames)), "max_frames": int(max(frames))}, frames
+
+    tts.respond("warm up " + emojis[0])
+    warm_texts = [make_text(int(torch.randint(17, 170, (1,), generator=g)), g) for _ in range(n_utt)]    # ~5.1 frames per character
+    _, seen = run(warm_texts)                                    # untimed pass: every warm length has now been planned once
+    torch.cuda.synchronize()
+    warm, _ = run(warm_texts)
+    g2 = torch.Generator().manual_seed(987)
+    cold_texts = [make_text(int(torch.randint(17, 170, (1,), generator=g2)), g2) for _ in range(n_utt)]
+    a0 = model.engine.alloc_count() + voc.engine.alloc_count()
+    cold, cold_frames = run(cold_texts)
+    cold["new_lengths"] = int(sum(1 for f in cold_frames if f not in set(seen)))
+    cold["allocs_during"] = int(model.engine.alloc_count() + voc.engine.alloc_count() - a0)
+    model.rng = rng_was
+    return {"utterances": n_utt, "note": "B=1, length_scale 0.8, 10 Euler steps, temperature 0.667, HiFi-GAN + clamp + denoiser; handles reserved for 1000 frames; lengths ~ U{86..860} frames (SURVEY 8d)",
+            "warm": warm, "cold_length": cold}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # config 2 / 3 (default)
 # ---------------------------------------------------------------------------------------------------------------------
 def close_models(*objs):
@@ -307,6 +393,7 @@ def main():
     ap.add_argument("--pipelines", type=int, default=2, help="batch pipelines in flight (each its own engine pair and two streams); "
                     "consecutive batches go to them in turn")
     ap.add_argument("--cpu-sample", type=int, default=8)
+    ap.add_argument("--no-extras", action="store_true", help="skip the compact config-4 / config-5 records of the default line")
     ap.add_argument("--plain", action="store_true", help="profiling aid: warm-up + K serial steps and nothing else (no roofline / CPU / PCIe legs), "
                     "so that a rocprofv3 --pmc pass sees exactly (W + K) x launches_per_step conv launches")
     args = ap.parse_args()
@@ -356,6 +443,9 @@ def main():
             p_.submit(mu, lengths, spk, z, n_ode)
             p_.synchronize()
     pipes = [] if pipe is None else pipe.pipes
+    # N > 1: the one collective of the path runs on ONE dedicated stream, ordered behind each batch's vocoder by an event (RCCL
+    # keeps per-stream state: alternating the pipelines' streams would serialise its kernels against both)
+    gather_stream = torch.cuda.Stream(device=device) if world > 1 else None
 
     def step():
         """-> (collated waveform of the global batch, this rank's waveform block, this rank's mel)"""
@@ -365,7 +455,9 @@ def main():
         wav, mel = pipe.submit(mu, lengths, spk, z, n_ode, return_mel=True)
         full = wav
         if world > 1:
-            with torch.cuda.stream(pipe.last.vocoder_stream):
+            gather_stream.wait_event(pipe.last.last_event)
+            with torch.cuda.stream(gather_stream):
+                wav.record_stream(gather_stream)
                 full = D.all_gather_waveforms(wav, B * world)
         return full, wav, mel
 
@@ -390,9 +482,27 @@ def main():
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
+    dt_rank = dt
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    per_rank_ms = [round(dt / args.steps * 1e3, 2)]
+    allgather_ms = None
     if world > 1:
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        # every rank's own time for the K steps (before the closing barrier it is the rank's compute + its share of the gathers)
+        trs = torch.zeros(world, dtype=torch.float64, device=device)
+        trs[rank] = dt_rank
+        torch.distributed.all_reduce(trs)
+        per_rank_ms = [round(float(v) / args.steps * 1e3, 2) for v in trs.tolist()]
+        # the collective alone: 5 gathers of this rank's last waveform block, nothing else in flight
+        torch.cuda.synchronize()
+        D.barrier()
+        tg = time.perf_counter()
+        for _ in range(5):
+            D.all_gather_waveforms(wav, B * world)
+        torch.cuda.synchronize()
+        tga = torch.tensor([(time.perf_counter() - tg) / 5 * 1e3], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tga, op=torch.distributed.ReduceOp.MAX)
+        allgather_ms = round(float(tga.item()), 3)
     dt = float(tmax.item())
     log(f"[bench] timed {args.steps} steps in {dt:.3f} s")
     audio_s_total = args.steps * B * world * T * HOP / SR
@@ -444,7 +554,7 @@ def main():
         per_gpu = value / world
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "kernel": "conv_gemm_kernel + resblock_pair_kernel + ln_mlp_kernel (fp32 v_mfma_f32_32x32x2_f32 implicit GEMM)",
+                    "kernel": "conv_gemm_kernel + resblock_pair_kernel + ln_mlp_kernel + attn_out_kernel (fp32 v_mfma_f32_32x32x2_f32 contractions)",
                     "schedule": "serial pass (one stream, stages back to back, see serial_ms_per_step); `value` is the two-stream pipeline",
                     "launches_per_step": int(conv_n), "avg_launch_us": round(conv_ms * 1e3 / max(conv_n, 1), 2),
                     "alg_gflop_per_launch": round(conv_fl / max(conv_n, 1) / 1e9, 3),
@@ -492,6 +602,15 @@ def main():
             cpu["parity_wav_rms"] = float((wav[:s].cpu() - ref_wav).pow(2).mean().sqrt())
             cpu["parity_wav_linf"] = float((wav[:s].cpu() - ref_wav).abs().max())
             cpu["parity_rows"] = f"rows 0..{s - 1} of the last timed step's output (batch {B})"
+        c4 = c5 = None
+        if world == 1 and not args.no_extras and B == 64 and T == 516:
+            if pipe is not None:
+                pipe.close()                                    # (gives the vocoder engine its small-call three-stream fan-out back)
+            try:
+                c4 = config4_record(sd, model, mu, z, spk, lengths, T)
+                c5 = config5_record(model, voc)
+            except Exception as ex:  # noqa: BLE001 - the headline line must not die with a side record
+                log(f"[bench] config-4 / config-5 records skipped: {type(ex).__name__}: {ex}")
         out = {
             "metric": "audio_seconds_per_second", "value": round(value, 2), "unit": "audio_s/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -499,12 +618,15 @@ def main():
             "config": {"workload": f"config2: batch {B} x {T}-frame (5.99 s) utterances per GPU, {n_ode} Euler steps + HiFi-GAN V1, 22.05 kHz",
                        "global_batch": B * world, "frames": T, "ode_steps": n_ode, "parallelism": f"dp{world}",
                        "collective": "all_gather(waveforms)" if world > 1 else "none",
-                       "batch_pipeline": "off" if pipe is None else f"cfm(i+1) || hifigan(i) on two streams, {len(pipes)} pipeline(s) in flight"},
-            "ranks_seen": ranks_seen, "gathered_shape": gathered_shape,
+                       "batch_pipeline": "off" if pipe is None else f"cfm(i+1) || hifigan(i) on two streams, {len(pipes)} pipeline(s) in flight",
+                       "memory": "off" if pipe is None else f"{len(pipes)} engine pairs resident per GPU, each its own weights (0.1 GB) + workspace "
+                                 f"({round(model.engine.workspace_bytes(B, T, 0) / 1e9 + voc.engine.workspace_bytes(B, 0, T) / 1e9, 1)} GB at this shape)"},
+            "ranks_seen": ranks_seen, "gathered_shape": gathered_shape, "per_rank_ms_per_step": per_rank_ms, "allgather_ms": allgather_ms,
             "per_gpu_audio_s_per_s": round(per_gpu, 2), "rtf": round(1.0 / per_gpu, 6), "x_realtime_per_gpu": round(per_gpu, 1),
             "serial_ms_per_step": round(serial_ms, 2), "batch_latency_ms": round(batch_latency_ms, 2), "stage_ms": stage_ms,
             "text_encoder": text_enc,
             "roofline": roofline, "path_roofline": path_roof, "cpu_baseline": cpu, "pcie_inclusive": pcie,
+            "config4": c4, "config5": c5,
         }
         print(json.dumps(out), flush=True)
     if world > 1:
