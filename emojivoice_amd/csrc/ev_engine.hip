@@ -147,6 +147,7 @@ struct ev_handle {
     unsigned* sk_ctrl = nullptr;    // [0] epoch [1] arrivals [2] timed-out waits | flags from word 16 on
     float* sk_part = nullptr;
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
+    bool sk_spread = false;         // EV_SK_SPREAD=1: launches of fewer row tiles than CUs (small batches) spread their units over up to 2 x CUs workgroups
     int sk_wgs = 2;                 // EV_SK_WGS=<1..3>: persistent workgroups per CU of a balanced ln_mlp launch (A/B runs)
     int sk_spin = 20000;            // EV_SK_SPIN=<polls> before an owner recomputes a contributor's share itself (~1.5 us per poll)
     int mrf_max_frames = 16384;     // EV_MRF_STREAMS_MAX=<B*T mel frames>: calls up to this size use the three streams (0 = never).  Six more scratch
@@ -464,6 +465,46 @@ void launch_sk(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     else launch_sk2<true, 0, TW>(p, st, lo);
 }
 
+constexpr int EV_CAPTURE_SLOTS = 8;       // captured ev_cfm_decode calls a handle can hold (pinned staging that is never recycled)
+constexpr int EV_SK_MAXWG = 1024;          // persistent workgroups of a balanced launch (<= 4 per CU on 256 CUs)
+constexpr int EV_SK_PART_FLOATS = 16384;   // largest partial accumulator tile handed over (64 KB: a 64 x 192 conv tile is 48 KB)
+// Hand-off area of the balanced launches: allocated once per handle (never inside a stream capture: ev_load_estimator calls this)
+int ensure_sk(ev_handle* h) {
+    if (h->sk_ctrl) return 0;
+    const size_t words = 16 + EV_SK_MAXWG;
+    HIPCHK(h, hipMalloc((void**)&h->sk_ctrl, words * sizeof(unsigned)));
+    HIPCHK(h, hipMemset(h->sk_ctrl, 0, words * sizeof(unsigned)));
+    HIPCHK(h, hipMalloc((void**)&h->sk_part, (size_t)EV_SK_MAXWG * 2 * EV_SK_PART_FLOATS * sizeof(float)));   // (freed by ev_destroy)
+    return 0;
+}
+
+// The balanced persistent build of a conv launch (conv_gemm_bal_kernel): G = wpc x CUs workgroups share the (tile, k-chunk) units.
+template <int BM, int BN, int WM, int WN>
+int launch_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
+    if (ensure_sk(h)) return 1;
+    const int nchunks = p.Kpad / EV_BK;
+    const long U = (long)p.mtiles * p.ntiles * nchunks;
+    const int G = wpc * h->ncu;
+    p.sk.ctrl = h->sk_ctrl; p.sk.flags = h->sk_ctrl + 16; p.sk.part = h->sk_part; p.sk.part_floats = EV_SK_PART_FLOATS;
+    p.sk.q = (int)(U / G); p.sk.r = (int)(U % G); p.sk.spin_limit = h->sk_spin;
+    const size_t xs = (size_t)(BN + ((lo.halo + 7) & ~7)) * 36;
+    constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4);
+    size_t smem = (xs > es ? xs : es) * sizeof(float);
+    p.sk.lds_word = (int)smem;
+    smem += 16;
+    if (lean_acc(p)) { ensure_dyn_smem<conv_gemm_bal_kernel<BM, BN, WM, WN, 3>>(smem, lo.device); hipLaunchKernelGGL((conv_gemm_bal_kernel<BM, BN, WM, WN, 3>), dim3(G), dim3(256), smem, h->stream, p); }
+    else { ensure_dyn_smem<conv_gemm_bal_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_gemm_bal_kernel<BM, BN, WM, WN, 1>), dim3(G), dim3(256), smem, h->stream, p); }
+    return 0;
+}
+// A conv launch takes the balanced build when it is dense (every tap in every M tile: equal units), has a lean non-transcendental
+// epilogue, fills at least one tile per CU and at most a few rounds (deep grids balance by themselves), and the tile's accumulators fit
+// a hand-off slot.
+inline bool bal_ok(const ev_handle* h, const ConvLayer& L, const ConvParams& p, long nwg, int wpc) {
+    static const bool off = getenv("EV_NO_CONV_BALANCE") != nullptr;
+    return !off && h->sk_balance && h->ncu > 0 && !L.sparse_taps && lean_ok(p) && p.act != ACT_SNAKE && !p.dbg && !p.stamps && !p.gn_part &&
+           nwg >= h->ncu && nwg < 4L * wpc * h->ncu && wpc * h->ncu <= EV_SK_MAXWG && (long)nwg * (p.Kpad / EV_BK) >= (long)wpc * h->ncu;
+}
+
 constexpr int EV_GN_MAXTILES = 256;    // 32-row tiles of a launch that may leave GroupNorm statistics (EstBufs::GNP)
 int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float* Y, int ldy, const Geom& g, const Epi& e) {
     ConvParams p;
@@ -587,7 +628,13 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         launch_cfg<64, 128, 2, 2>(p, h->stream, lo);
     } else if (cfg == 5) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<64, 192, 2, 2>(p, h->stream, lo);
+        static const int bal5 = getenv("EV_BAL5") ? atoi(getenv("EV_BAL5")) : 0;      // A/B: 0 = as is, 192 = balanced 64 x 192, 64 = balanced 64 x 64
+        if (bal5 == 192 && lo.kb == 1 && bal_ok(h, L, p, (long)p.mtiles * p.ntiles, 3)) { if (launch_bal<64, 192, 2, 2>(h, p, lo, 3)) return 1; cfg = 55; }
+        else if (bal5 == 64 && lo.kb == 1 && bal_ok(h, L, p, (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64), 4)) {
+            p.ntiles = (g.nrows + 63) / 64;
+            if (launch_bal<64, 64, 2, 2>(h, p, lo, 4)) return 1;
+            cfg = 56;
+        } else launch_cfg<64, 192, 2, 2>(p, h->stream, lo);
     } else if (cfg == 7) {   // 64 x 192 with register-prefetched X staging
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<64, 192, 2, 2, true>(p, h->stream, lo);
@@ -623,7 +670,8 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         } else launch_sk<1>(p, h->stream, lo);
     } else if (cfg == 6) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_cfg<64, 64, 2, 2>(p, h->stream, lo);
+        if (lo.kb == 1 && bal_ok(h, L, p, (long)p.mtiles * p.ntiles, 4)) { if (launch_bal<64, 64, 2, 2>(h, p, lo, 4)) return 1; cfg = 56; }
+        else launch_cfg<64, 64, 2, 2>(p, h->stream, lo);
     } else if (cfg == 10 && !L.sparse_taps && L.Mpad % 128 == 0) {   // 128 x 192: less halo per MFMA for the wide-halo layers at Cout = 128
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = 0;
         launch_cfg<128, 192, 2, 2>(p, h->stream, lo);
@@ -748,19 +796,6 @@ int launch_ln(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const fl
     return 0;
 }
 
-constexpr int EV_CAPTURE_SLOTS = 8;       // captured ev_cfm_decode calls a handle can hold (pinned staging that is never recycled)
-constexpr int EV_SK_MAXWG = 1024;          // persistent workgroups of a balanced launch (<= 4 per CU on 256 CUs)
-constexpr int EV_SK_PART_FLOATS = 16384;   // largest partial accumulator tile handed over (64 KB: a 64 x 192 conv tile is 48 KB)
-// Hand-off area of the balanced launches: allocated once per handle (never inside a stream capture: ev_load_estimator calls this)
-int ensure_sk(ev_handle* h) {
-    if (h->sk_ctrl) return 0;
-    const size_t words = 16 + EV_SK_MAXWG;
-    HIPCHK(h, hipMalloc((void**)&h->sk_ctrl, words * sizeof(unsigned)));
-    HIPCHK(h, hipMemset(h->sk_ctrl, 0, words * sizeof(unsigned)));
-    HIPCHK(h, hipMalloc((void**)&h->sk_part, (size_t)EV_SK_MAXWG * 2 * EV_SK_PART_FLOATS * sizeof(float)));   // (freed by ev_destroy)
-    return 0;
-}
-
 // LayerNorm + feed-forward (mode 0) or LayerNorm + QKV projection (mode 1) of one transformer block in one launch
 // (ln_mlp_kernel).  Counted as ONE conv launch of the dominant-kernel family by the profiling hooks (its FLOPs are those of
 // the linears it contains).
@@ -796,10 +831,12 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
     mp.ntiles = ntiles;
     mp.sk.q = nchunk; mp.sk.r = 0; mp.sk.spin_limit = h->sk_spin;
     const int wpc = h->sk_wgs;
-    if (h->sk_balance && h->ncu > 0 && ntiles >= h->ncu && wpc * h->ncu <= EV_SK_MAXWG && (long)ntiles * nchunk >= (long)wpc * h->ncu) {
+    const bool big = ntiles >= h->ncu && (long)ntiles * nchunk >= (long)wpc * h->ncu;
+    const bool spread = !big && h->sk_spread && ntiles < h->ncu && (long)ntiles * nchunk >= 2;   // small batches: one or a few units per workgroup
+    if (h->sk_balance && h->ncu > 0 && wpc * h->ncu <= EV_SK_MAXWG && (big || spread)) {
         if (ensure_sk(h)) return 1;
-        grid = wpc * h->ncu;
         const long U = (long)ntiles * nchunk;
+        grid = (int)std::min<long>((long)wpc * h->ncu, U);
         mp.sk.q = (int)(U / grid); mp.sk.r = (int)(U % grid);
         mp.sk.ctrl = h->sk_ctrl; mp.sk.flags = h->sk_ctrl + 16; mp.sk.part = h->sk_part; mp.sk.part_floats = EV_SK_PART_FLOATS;
         // three per CU: the LDS request is padded so that exactly three fit.  Two per CU (the default): the 256-register build admits
@@ -1079,7 +1116,7 @@ int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z,
     Epi e;
     // row tiles of 32 frames: the fused LayerNorm + linear kernels need about a round of workgroups to pay off (a batch-1
     // decode has 9-27 such tiles: it keeps the split-K small-launch build of the separate linears)
-    const bool fuse = h->fuse_mlp && (g_rows32(L.g) >= h->fuse_mlp_min_tiles);
+    const bool fuse = h->fuse_mlp && (g_rows32(L.g) >= h->fuse_mlp_min_tiles || (h->sk_spread && h->sk_balance));
     if (fuse) {
         if (launch_mlp(h, 1, L.H, w.ln1g, w.ln1b, w.qkv, nullptr, nullptr, nullptr, nullptr, nullptr, L.QKV, 384, L.g)) return 1;
     } else {
@@ -1427,6 +1464,7 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     { const char* fp = getenv("EV_NO_SK_BALANCE"); if (fp && *fp && *fp != '0') h->sk_balance = false; }
     { const char* fp = getenv("EV_SK_SPIN"); if (fp && *fp) h->sk_spin = atoi(fp); }
     { const char* fp = getenv("EV_SK_WGS"); if (fp && *fp) h->sk_wgs = std::min(3, std::max(1, atoi(fp))); }
+    { const char* fp = getenv("EV_SK_SPREAD"); if (fp && *fp) h->sk_spread = *fp != '0'; }
     if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) h->ncu = 0;
     // the shipped decoder configuration (configs/model/decoder/default.yaml: 2 heads x 64) is the only one the workspace
     // plan and the transformer launch sequence are laid out for
@@ -1962,7 +2000,16 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
     // nothing else to enqueue for this utterance anyway — and only then fans out.
     if (ms) HIPCHK(h, hipStreamSynchronize(h->stream));
     hipStream_t s0 = h->stream;
-    struct StreamGuard { ev_handle* h; hipStream_t s; ~StreamGuard() { h->stream = s; } } guard{h, s0};
+    // (the fan-out runs three chains of this handle concurrently: the balanced builds' hand-off area — one per handle, launches
+    // ordered by ONE stream — is off limits for them; a failure between fork and join waits for the side streams before returning)
+    struct StreamGuard {
+        ev_handle* h; hipStream_t s; bool bal; bool ms; bool done;
+        ~StreamGuard() {
+            h->stream = s; h->sk_balance = bal;
+            if (ms && !done) { for (int c = 0; c < 2; ++c) if (h->mrf_stream[c]) (void)hipStreamSynchronize(h->mrf_stream[c]); }
+        }
+    } guard{h, s0, h->sk_balance, ms, false};
+    if (ms) h->sk_balance = false;
     for (int i = 0; i < 4; ++i) {
         const int l = i + 1, C = w.ch[l], s = w.ups[i].Cout / C;
         {   // transposed conv: input frames of level l-1 -> view rows of s output frames each
@@ -2020,6 +2067,7 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
             HIPCHK(h, hipGetLastError());
         }
     }
+    guard.done = true;
     return 0;
 }
 

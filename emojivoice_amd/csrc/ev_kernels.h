@@ -33,6 +33,16 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_SILU = 3, ACT_MISH = 4, ACT_SNAKE = 5 };
 
+struct SkCtl {
+    unsigned* ctrl;      // [0] epoch, [1] arrivals of the running launch, [2] waits that ran out (diagnostic); null = no hand-offs
+    unsigned* flags;     // one word per workgroup: tag of the launch whose partial is in that workgroup's slot
+    float* part;         // per workgroup: two tiles of `part_floats` (published partial | private spill of the fallback path)
+    int part_floats;
+    int q, r;            // units per workgroup: start(x) = x * q + min(x, r)
+    int spin_limit;      // polls before an owner gives up waiting
+    int lds_word;        // conv_gemm_bal_kernel: byte offset of the sk_wait word in dynamic LDS
+};
+
 struct ConvParams {
     const float* X; int ldx; int Cin;
     int isplit_log2, isstride;              // input column ci lives at (ci >> isplit_log2)*isstride + (ci & (2^isplit_log2 - 1))
@@ -65,6 +75,7 @@ struct ConvParams {
     int stagger_slots;                      // workgroups co-resident per CU (0 = no start stagger), see conv_gemm_kernel
     unsigned long long* stamps;             // dbg bit 16: per-workgroup {start, first stage done, K loop done, end} s_memtime stamps
     int dbg;                                // ablation bits for tools/conv_bench.py: 1 skip X loads, 2 skip A loads, 4 skip epilogue
+    SkCtl sk;                               // conv_gemm_kernel<..., SK = true>: the balanced persistent grid (units = (tile, 32-channel k-chunk))
 };
 
 
@@ -395,6 +406,93 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     }
 }
 
+// ---------------------------------------------------------------------------
+// Balanced work assignment inside ONE launch ("stream-K").  The U-Net launches of a batch-64 decode are about one round of
+// workgroups, so a launch lasts as long as its busiest CU: 520 row tiles of a feed-forward on 256 CUs leave eight CUs with three
+// tiles while the others hold two (measured with tools/shape_profile.py: 62 utterances — 504 tiles — decode 14 % faster than
+// 64 for 3 % less work).  Here a launch is G persistent workgroups (G = CUs x workgroups that fit a CU), the work is cut into
+// UNITS finer than a tile (a feed-forward row tile = 8 hidden-width chunks), and workgroup g takes the contiguous unit range
+// [start(g), start(g + 1)), start(x) = x * q + min(x, r) with q = U / G, r = U % G.  A tile whose units straddle two (or three)
+// workgroups is finished by the OWNER — the workgroup holding its first unit, which reaches it LAST in its own range — the others
+// reach their share of it FIRST and publish an un-biased partial accumulator tile, which the owner adds in ascending workgroup
+// order (deterministic).  Hand-off = MI355X guide, Guideline 16 R1: write-through (sc1) payload stores, every storing wave drains
+// vmcnt, workgroup barrier, ONE lane stores the flag with an agent-scope atomic; the consumer polls that word relaxed, ONE agent
+// acquire, barrier, then sc1 loads.  Flags carry a launch tag (device-side epoch word + 1, bumped by the last workgroup to
+// arrive at the end of the launch), so nothing has to be zeroed per launch and a replayed hipGraph stays correct.
+// No protocol step depends on dispatch order or residency: a publisher never waits before it publishes, and an owner whose wait
+// runs out (a contributor that is not resident yet) recomputes the missing share itself AS A SEPARATE partial sum, i.e. with
+// the bits the contributor would have delivered — slower, never different, never a hang.
+// ---------------------------------------------------------------------------
+typedef __attribute__((address_space(1))) unsigned ev_gu32;
+__device__ __forceinline__ int sk_start(const SkCtl& c, int x) { return x * c.q + (x < c.r ? x : c.r); }
+__device__ __forceinline__ unsigned sk_tag(const SkCtl& c) {
+    return c.ctrl ? (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((ev_gu32*)c.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u : 0u;
+}
+__device__ __forceinline__ f32x4 ev_bload4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, 0, 16));    // aux 16 = sc1: served by L2, never a stale L1 line
+}
+__device__ __forceinline__ void ev_bstore4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff_bytes, 0, 16);       // write-through
+}
+// after every wave's payload stores: drain, meet, ONE lane raises the flag
+__device__ __forceinline__ void sk_publish(const SkCtl& c, int g, unsigned tag, int tid) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (tid == 0) __hip_atomic_store((ev_gu32*)(c.flags + g), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// true when workgroup gi's partial of this launch is readable by every wave of the caller (all threads must call; `word` = one LDS int)
+__device__ __forceinline__ bool sk_wait(const SkCtl& c, int gi, unsigned tag, int tid, int* word) {
+    if (tid == 0) {
+        int ok = 0;
+        for (int spins = 0; spins < c.spin_limit; ++spins) {
+            if (__hip_atomic_load((ev_gu32*)(c.flags + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (!ok) atomicAdd(c.ctrl + 2, 1u);
+        *word = ok;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // (readfirstlane: the result steers wave-uniform control flow — chunk ranges, hence descriptor offsets of the fragment loads;
+    // read as a plain LDS value it made hipcc treat all of that as divergent and wrap every buffer load of the K loops in a waterfall loop)
+    const bool ok = __builtin_amdgcn_readfirstlane(*word) != 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (the word may be rewritten by the next wait)
+    return ok;
+}
+// The same for the n (<= 64) consecutive workgroups gi .. gi + n - 1: lane k of wave 0 polls flag gi + k, so the flags are read in parallel
+// and ONE acquire covers them all.  Returns how many LEADING flags were up when the polling ended (n, or fewer after the spin limit).
+__device__ __forceinline__ int sk_wait_many(const SkCtl& c, int gi, int n, unsigned tag, int tid, int* word) {
+    if (tid < 64) {                                    // wave 0 (a whole wave: scalar branch)
+        unsigned long long up = 0;
+        const unsigned long long want = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        for (int spins = 0; spins < c.spin_limit; ++spins) {
+            const unsigned v = tid < n ? __hip_atomic_load((ev_gu32*)(c.flags + gi + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
+            up = __ballot(v == tag);
+            if ((up & want) == want) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const unsigned long long miss = ~up & want;
+        const int ready = miss ? __builtin_ctzll(miss) : n;
+        if (tid == 0) {
+            if (ready < n) atomicAdd(c.ctrl + 2, 1u);
+            *word = ready;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int ready = __builtin_amdgcn_readfirstlane(*word);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    return ready;
+}
+// end of the launch: the last workgroup to arrive advances the epoch (next launch: tag + 1) and re-arms the counter
+__device__ __forceinline__ void sk_arrive(const SkCtl& c, unsigned tag, int tid) {
+    if (!c.ctrl || tid != 0) return;
+    const unsigned old = __hip_atomic_fetch_add((ev_gu32*)(c.ctrl + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == gridDim.x) {
+        __hip_atomic_store((ev_gu32*)(c.ctrl + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((ev_gu32*)c.ctrl, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // KB = 32-channel k-chunks staged per barrier pair (LDS row = 32*KB + 4 floats).  KB = 2 halves the number of
 // stage / barrier episodes — what the 1x1 and k=3 layers need (a 1x1 conv has only 4 k-groups = 32 MFMAs per wave
 // between two barrier pairs at KB = 1); wide-halo layers (k = 11, d = 5) already run 352 MFMAs per chunk and keep KB = 1
@@ -654,6 +752,247 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     else conv_epilogue<TM, TN, FULL_ACT>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ---------------------------------------------------------------------------
+// conv_gemm_bal_kernel: conv_gemm_kernel for launches of about ONE ROUND of workgroups (the U-Net convs of a batch-64 decode), as
+// a balanced persistent grid (SkCtl above): G workgroups, a unit = (tile, 32-channel k-chunk), workgroup g takes the contiguous
+// unit range [start(g), start(g + 1)) in (tile-major, chunk-minor) order.  A tile whose chunks straddle workgroups is finished by
+// the one that holds chunk 0 (it reaches that tile LAST; bias in its accumulators), the others reach their share of it FIRST and
+// hand over an accumulator tile without bias; the owner adds them in ascending workgroup order.  Same K loop as conv_gemm_kernel
+// (KB = 1, no register-prefetched staging), lean epilogues only; the summation order over k-chunks of a split tile differs from
+// the one-tile-per-workgroup build (partial sums), deterministically for a given device.
+// Measured motive (tools/shape_profile.py, 62 vs 64 utterances): 1040 tiles of 64 x 64 on 256 CUs leave the matrix pipes of three
+// quarters of the chip idle for the last fifth of the launch (4.06 tiles per CU = five rounds on some CUs).
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN>
+__global__ __launch_bounds__(256, 3) void conv_gemm_bal_kernel(const ConvParams p) {
+    constexpr int TM = BM / WAVES_M / 32;
+    constexpr int TN = BN / WAVES_N / 32;
+    constexpr int LDK = 36;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1 && LEAN != 0, "balanced build: 4 waves, lean epilogue");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Xs = smem;                                  // [(BN + halo)][LDK]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nchunks = p.Kpad / EV_BK;
+    const int g = blockIdx.x;
+    const unsigned tag = sk_tag(p.sk);
+    int u = sk_start(p.sk, g);
+    const int ue = sk_start(p.sk, g + 1);
+    const __amdgpu_buffer_rsrc_t rPart = ev_rsrc(p.sk.part), rW = ev_rsrc(p.W), rX = ev_rsrc(p.X);
+    const unsigned pslot = (unsigned)p.sk.part_floats * 8u;                  // bytes per workgroup: [published partial | private spill]
+    constexpr int PN = TM * TN * 4;                                          // float4 of the accumulator tile per lane
+    const unsigned pelem = (unsigned)(wave * PN) * 1024u + (unsigned)lane * 16u;
+    int* skw = (int*)((char*)smem + p.sk.lds_word);                          // one word for sk_wait, behind everything else in LDS
+    bool pend_pub = false;
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int KG8 = p.Kpad >> 3;
+    constexpr int TPR = 8, RPS = 256 / TPR;
+    const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
+    constexpr int XPASS = (BN + EV_HALO) / RPS;
+    constexpr int XG = XPASS > 8 ? 8 : XPASS;
+    const int xrows = BN + p.halo_lo + p.halo_hi;
+    const int npass = (xrows + RPS - 1) / RPS;
+
+    while (u < ue) {
+        const int t = u / nchunks, c0 = u - t * nchunks;
+        const int c1 = (ue - u < nchunks - c0) ? c0 + (ue - u) : nchunks;
+        u += c1 - c0;
+        const int mt = t % p.mtiles, nt = t / p.mtiles;
+        const int m0 = mt * BM, n0 = nt * BN;
+        {   // tiles that contain no storable row (pure padding) do nothing — owner and contributors agree, the test only reads t
+            int t_first = (n0 % p.S) - p.P;
+            int dist;
+            if (t_first >= 0 && t_first < p.T) dist = 0;
+            else if (t_first < 0) dist = -t_first;
+            else dist = p.S - (n0 % p.S) + p.P;
+            if (dist >= BN || n0 + dist >= p.nrows) continue;
+        }
+        if (pend_pub) { sk_publish(p.sk, g, tag, tid); pend_pub = false; }   // the previous segment's partial tile: drain, then raise its flag
+        const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
+        const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
+        const int mt32 = (m0 + wm * (TM * 32)) >> 5;
+        const unsigned wbase = (unsigned)(mt32 * KG8) * 1024u;
+        auto a_off = [&](int tap_bytes, int kg8) -> unsigned { return (unsigned)tap_bytes + wbase + (unsigned)kg8 * 1024u; };
+        f32x4 A0[TM], A1[TM], A2[TM], A3[TM], B0[TN], B1[TN];
+        auto ldAp = [&](f32x4 (&dst)[TM], unsigned aoff) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) dst[i] = ev_bload4(rW, wlane, aoff + (unsigned)(i * KG8 * 1024));
+        };
+        auto ldB = [&](f32x4 (&dst)[TN], const float* brow, int kg) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dst[j] = *(const f32x4*)(brow + j * 32 * LDK + kg * 8);
+        };
+        const float* bbase = Xs + (wn * (TN * 32) + li + p.halo_lo) * LDK + 4 * lh;
+        const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
+        const int2 tv_first = ev_tap_at(tlv, 0);
+        unsigned xoff[XPASS];
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) {
+            const int gr = n0 - p.halo_lo + q * RPS + srow;
+            xoff[q] = ((q < npass && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
+        }
+        auto x_soff = [&](int ch) -> unsigned {
+            const int cc = ch * EV_BK;
+            return ((unsigned)(cc >> p.isplit_log2) * p.isstride + (unsigned)(cc & ((1 << p.isplit_log2) - 1))) * 4u;
+        };
+        auto x_put = [&](int q, f32x4 v, int cc, bool ctail) {
+            const int r = q * RPS + srow;
+            if (ctail && cc + sc4 >= p.Cin) { v[0] = 0.f; v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }
+            if (p.pro_lrelu) {
+                v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+            }
+            if (r < xrows) *(f32x4*)(Xs + r * LDK + sc4) = v;
+        };
+
+        // ---- passes over chunk ranges of this tile (see ln_mlp_kernel): [c0, c1) first; an owner whose wait for a contributor ran
+        // out adds one pass over that contributor's range with fresh accumulators (the contributor's bits)
+        int cA = c0, cB = c1;
+        bool spilled = false;
+        int gi = g + 1;
+        const int tile_end = (t + 1) * nchunks;
+        for (;;) {
+            f32x16 acc[TM][TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                f32x4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    bq[q] = z;
+                    const int cc = m0 + wm * (TM * 32) + a * 32 + 8 * q + 4 * lh;   // bias preloaded (lean epilogue), by the owner's first pass only
+                    if (p.bias && cA == 0 && cc < p.Cout) bq[q] = *(const f32x4*)(p.bias + cc);
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = bq[r >> 2][r & 3];
+            }
+            auto mma = [&](const f32x4 (&a)[TM], const f32x4 (&b)[TN]) {
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s4], b[j][s4], acc[i][j], 0, 0, 0);
+            };
+            if (nact > 0) {
+                const unsigned a0 = a_off(tv_first.x, cA * 4);
+                ldAp(A0, a0); ldAp(A1, a0 + 1024u); ldAp(A2, a0 + 2048u); ldAp(A3, a0 + 3072u);
+            }
+            for (int ch = cA; ch < cB; ++ch) {
+                __builtin_amdgcn_s_setprio(3);
+                ev_lds_barrier();                          // the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
+                {
+                    const int cc = ch * EV_BK;
+                    const bool ctail = (cc + 32 > p.Cin);
+                    const unsigned soff = x_soff(ch);
+#pragma unroll
+                    for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                        if (q0 * RPS >= xrows) continue;
+                        f32x4 xg[XG];
+#pragma unroll
+                        for (int q = 0; q < XG; ++q) {
+                            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                            if ((q0 + q) * RPS < xrows) v = ev_bload4(rX, xoff[q0 + q], soff);
+                            xg[q] = v;
+                        }
+#pragma unroll
+                        for (int q = 0; q < XG; ++q) x_put(q0 + q, xg[q], cc, ctail);
+                    }
+                }
+                ev_lds_barrier();
+                __builtin_amdgcn_s_setprio(0);
+                const float* brow = bbase + tv_first.y * LDK;
+                ldB(B0, brow, 0);
+                for (int ti = 0; ti < nact; ++ti) {
+                    const bool last_tap = (ti + 1 == nact);
+                    const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
+                    const float* nbrow = bbase + ntv.y * LDK;
+                    const bool have_next = !(last_tap && ch + 1 == cB);
+                    const unsigned nap = have_next ? a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4) : a_off(tv_first.x, cA * 4);
+                    ldB(B1, brow, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(A0, B0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A0, nap);
+                    ldB(B0, brow, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(A1, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A1, nap + 1024u);
+                    ldB(B1, brow, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(A2, B0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A2, nap + 2048u);
+                    ldB(B0, nbrow, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(A3, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A3, nap + 3072u);
+                    brow = nbrow;
+                }
+            }
+            auto acc_io = [&](unsigned base, int mode) {    // mode 0: store (write-through), 1: add from memory
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned off = base + pelem + (unsigned)((a * TN + b) * 4 + q) * 1024u;
+                            if (mode == 0) {
+                                const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                                ev_bstore4_sc1(rPart, off, v);
+                            } else {
+                                const f32x4 v = ev_bload4_sc1(rPart, off);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[a][b][4 * q + e] += v[e];
+                            }
+                        }
+            };
+            if (spilled) { acc_io((unsigned)g * pslot + pslot / 2, 1); spilled = false; }   // running sum (spilled) + this contributor's share
+            if (c0 != 0) {                                 // not the owner: hand the partial tile over (flag raised at the next segment)
+                acc_io((unsigned)g * pslot, 0);
+                pend_pub = true;
+                break;
+            }
+            bool again = false;
+            while (c1 < nchunks) {                         // owner: add the contributors' partial tiles in ascending workgroup order
+                int n = 0;
+                while (n < 64 && gi + n < (int)gridDim.x && sk_start(p.sk, gi + n) < tile_end) ++n;
+                if (n == 0) break;
+                const int ready = sk_wait_many(p.sk, gi, n, tag, tid, skw);
+                for (int k = 0; k < ready; ++k) acc_io((unsigned)(gi + k) * pslot, 1);
+                gi += ready;
+                if (ready < n) {                           // gi is not there in time: spill the running sum, compute its share here
+                    const int sgi = sk_start(p.sk, gi);
+                    int egi = sk_start(p.sk, gi + 1);
+                    egi = egi < tile_end ? egi : tile_end;
+                    acc_io((unsigned)g * pslot + pslot / 2, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    cA = sgi - t * nchunks; cB = egi - t * nchunks;
+                    spilled = true; again = true;
+                    ++gi;
+                    break;
+                }
+            }
+            if (again) continue;
+            __builtin_amdgcn_s_setprio(3);
+            conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+            __builtin_amdgcn_s_setprio(0);
+            break;
+        }
+    }
+    if (pend_pub) sk_publish(p.sk, g, tag, tid);
+    sk_arrive(p.sk, tag, tid);
 }
 
 // (A loader-wave build of this kernel — two extra waves per workgroup that only stage X tiles, so that the MFMA waves
@@ -1492,76 +1831,6 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const LNParams p) {
 // HBM.  Accumulation order over k is the unfused kernels' (bias first, k ascending), so results are bit-identical to them.
 // Weights stream from L2 in MFMA-fragment order as in conv_gemm_kernel, four k-groups ahead.
 // ---------------------------------------------------------------------------
-// ---------------------------------------------------------------------------
-// Balanced work assignment inside ONE launch ("stream-K").  The U-Net launches of a batch-64 decode are about one round of
-// workgroups, so a launch lasts as long as its busiest CU: 520 row tiles of a feed-forward on 256 CUs leave eight CUs with three
-// tiles while the others hold two (measured with tools/shape_profile.py: 62 utterances — 504 tiles — decode 14 % faster than
-// 64 for 3 % less work).  Here a launch is G persistent workgroups (G = CUs x workgroups that fit a CU), the work is cut into
-// UNITS finer than a tile (a feed-forward row tile = 8 hidden-width chunks), and workgroup g takes the contiguous unit range
-// [start(g), start(g + 1)), start(x) = x * q + min(x, r) with q = U / G, r = U % G.  A tile whose units straddle two (or three)
-// workgroups is finished by the OWNER — the workgroup holding its first unit, which reaches it LAST in its own range — the others
-// reach their share of it FIRST and publish an un-biased partial accumulator tile, which the owner adds in ascending workgroup
-// order (deterministic).  Hand-off = MI355X guide, Guideline 16 R1: write-through (sc1) payload stores, every storing wave drains
-// vmcnt, workgroup barrier, ONE lane stores the flag with an agent-scope atomic; the consumer polls that word relaxed, ONE agent
-// acquire, barrier, then sc1 loads.  Flags carry a launch tag (device-side epoch word + 1, bumped by the last workgroup to
-// arrive at the end of the launch), so nothing has to be zeroed per launch and a replayed hipGraph stays correct.
-// No protocol step depends on dispatch order or residency: a publisher never waits before it publishes, and an owner whose wait
-// runs out (a contributor that is not resident yet) recomputes the missing share itself AS A SEPARATE partial sum, i.e. with
-// the bits the contributor would have delivered — slower, never different, never a hang.
-// ---------------------------------------------------------------------------
-struct SkCtl {
-    unsigned* ctrl;      // [0] epoch, [1] arrivals of the running launch, [2] waits that ran out (diagnostic); null = no hand-offs
-    unsigned* flags;     // one word per workgroup: tag of the launch whose partial is in that workgroup's slot
-    float* part;         // per workgroup: two tiles of `part_floats` (published partial | private spill of the fallback path)
-    int part_floats;
-    int q, r;            // units per workgroup: start(x) = x * q + min(x, r)
-    int spin_limit;      // polls before an owner gives up waiting
-};
-typedef __attribute__((address_space(1))) unsigned ev_gu32;
-__device__ __forceinline__ int sk_start(const SkCtl& c, int x) { return x * c.q + (x < c.r ? x : c.r); }
-__device__ __forceinline__ unsigned sk_tag(const SkCtl& c) {
-    return c.ctrl ? (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((ev_gu32*)c.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u : 0u;
-}
-__device__ __forceinline__ f32x4 ev_bload4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, 0, 16));    // aux 16 = sc1: served by L2, never a stale L1 line
-}
-__device__ __forceinline__ void ev_bstore4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff_bytes, 0, 16);       // write-through
-}
-// after every wave's payload stores: drain, meet, ONE lane raises the flag
-__device__ __forceinline__ void sk_publish(const SkCtl& c, int g, unsigned tag, int tid) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (tid == 0) __hip_atomic_store((ev_gu32*)(c.flags + g), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// true when workgroup gi's partial of this launch is readable by every wave of the caller (all threads must call; `word` = one LDS int)
-__device__ __forceinline__ bool sk_wait(const SkCtl& c, int gi, unsigned tag, int tid, int* word) {
-    if (tid == 0) {
-        int ok = 0;
-        for (int spins = 0; spins < c.spin_limit; ++spins) {
-            if (__hip_atomic_load((ev_gu32*)(c.flags + gi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(16);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (!ok) atomicAdd(c.ctrl + 2, 1u);
-        *word = ok;
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // (readfirstlane: the result steers wave-uniform control flow — chunk ranges, hence descriptor offsets of the fragment loads;
-    // read as a plain LDS value it made hipcc treat all of that as divergent and wrap every buffer load of the K loops in a waterfall loop)
-    const bool ok = __builtin_amdgcn_readfirstlane(*word) != 0;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (the word may be rewritten by the next wait)
-    return ok;
-}
-// end of the launch: the last workgroup to arrive advances the epoch (next launch: tag + 1) and re-arms the counter
-__device__ __forceinline__ void sk_arrive(const SkCtl& c, unsigned tag, int tid) {
-    if (!c.ctrl || tid != 0) return;
-    const unsigned old = __hip_atomic_fetch_add((ev_gu32*)(c.ctrl + 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (old + 1 == gridDim.x) {
-        __hip_atomic_store((ev_gu32*)(c.ctrl + 1), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store((ev_gu32*)c.ctrl, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
-
 struct MlpParams {
     ConvParams ep;                 // epilogue view of the LAST linear: Y / ldy / Cout / bias, R / ldr, rowmask / mask2, nrows / S / P / T
     const float* X; int ldx;       // (rows, 256) input of the LayerNorm
@@ -1856,36 +2125,39 @@ __global__ __launch_bounds__(256, WPC) void ln_mlp_kernel(const MlpParams mp) {
                     }
                 }
                 while (c1 < nchunk) {
-                    const int s = sk_start(mp.sk, gi);
-                    if (s >= tile_end) break;
-                    int e = sk_start(mp.sk, gi + 1);
-                    e = e < tile_end ? e : tile_end;
-                    if (e > s) {
-                        if (sk_wait(mp.sk, gi, tag, tid, skw)) {
+                    // the workgroups gi .. gi + n - 1 hold the rest of this tile (every workgroup holds at least one unit)
+                    int n = 0;
+                    while (n < 64 && gi + n < (int)gridDim.x && sk_start(mp.sk, gi + n) < tile_end) ++n;
+                    if (n == 0) break;
+                    const int ready = sk_wait_many(mp.sk, gi, n, tag, tid, skw);
+                    for (int k = 0; k < ready; ++k) {
 #pragma unroll
-                            for (int a = 0; a < 2; ++a)
+                        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const f32x4 v = ev_bload4_sc1(rPart, (unsigned)gi * pslot + pelem + (unsigned)(a * 4 + q) * 1024u);
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = ev_bload4_sc1(rPart, (unsigned)(gi + k) * pslot + pelem + (unsigned)(a * 4 + q) * 1024u);
 #pragma unroll
-                                    for (int e2 = 0; e2 < 4; ++e2) acc2[a][0][4 * q + e2] += v[e2];
-                                }
-                        } else {                       // not there in time: spill the running sum, compute that share here
-#pragma unroll
-                            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const f32x4 v = {acc2[a][0][4 * q], acc2[a][0][4 * q + 1], acc2[a][0][4 * q + 2], acc2[a][0][4 * q + 3]};
-                                    ev_bstore4_sc1(rPart, (unsigned)g * pslot + pslot / 2 + pelem + (unsigned)(a * 4 + q) * 1024u, v);
-                                }
-                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                            cA = s - t * nchunk; cB = e - t * nchunk;
-                            spilled = true; again = true;
-                            ++gi;
-                            break;
-                        }
+                                for (int e2 = 0; e2 < 4; ++e2) acc2[a][0][4 * q + e2] += v[e2];
+                            }
                     }
-                    ++gi;
+                    gi += ready;
+                    if (ready < n) {                       // gi is not there in time: spill the running sum, compute its share here
+                        const int s = sk_start(mp.sk, gi);
+                        int e = sk_start(mp.sk, gi + 1);
+                        e = e < tile_end ? e : tile_end;
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4 v = {acc2[a][0][4 * q], acc2[a][0][4 * q + 1], acc2[a][0][4 * q + 2], acc2[a][0][4 * q + 3]};
+                                ev_bstore4_sc1(rPart, (unsigned)g * pslot + pslot / 2 + pelem + (unsigned)(a * 4 + q) * 1024u, v);
+                            }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        cA = s - t * nchunk; cB = e - t * nchunk;
+                        spilled = true; again = true;
+                        ++gi;
+                        break;
+                    }
                 }
                 if (again) {
                     F0 = ldP(cA * 4 + wave, 0); F1 = ldP(cA * 4 + wave, 1); F2 = ldP(cA * 4 + wave, 2); F3 = ldP(cA * 4 + wave, 3);

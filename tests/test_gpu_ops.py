@@ -55,6 +55,42 @@ def test_conv1d(eng, B, Cin, T, Cout, K, dil, slope):
     _close(got, ref, what=f"conv {Cin}->{Cout} k{K} d{dil}")
 
 
+@pytest.mark.parametrize("B,Cin,T,Cout,K,slope", [(64, 256, 196, 256, 3, -1.0), (64, 256, 194, 256, 3, 0.1), (64, 512, 196, 256, 1, -1.0), (48, 256, 283, 256, 3, -1.0)])
+def test_conv1d_balanced_grid(eng, B, Cin, T, Cout, K, slope, monkeypatch):
+    """Dense conv launches of about one round of workgroups take conv_gemm_bal_kernel (a balanced persistent grid over (tile,
+    k-chunk) units with in-launch hand-off of partial accumulator tiles, SkCtl in ev_kernels.h): against torch, against a handle
+    whose owners never wait (EV_SK_SPIN=0: every hand-off takes the recompute path and must deliver the same bits), launch after
+    launch, and against the one-tile-per-workgroup build."""
+    from emojivoice_amd._lib import Engine
+
+    g = torch.Generator().manual_seed(B + Cin + T)
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    pad = (K - 1) // 2
+    xin = F.leaky_relu(x, slope) if slope >= 0 else x
+    ref = F.conv1d(xin, w, b, padding=pad)
+    s0 = eng.sk_stats()[0]
+    got = eng.op_conv1d(x.cuda(), w, b, padding=pad, pre_lrelu_slope=slope)
+    assert eng.sk_stats()[0] == s0 + 1, "this shape was expected to take the balanced build"
+    _close(got, ref, what=f"balanced conv {Cin}->{Cout} k{K}")
+    for _ in range(2):
+        assert torch.equal(eng.op_conv1d(x.cuda(), w, b, padding=pad, pre_lrelu_slope=slope), got)
+    monkeypatch.setenv("EV_SK_SPIN", "0")
+    e2 = Engine(0)
+    try:
+        assert torch.equal(e2.op_conv1d(x.cuda(), w, b, padding=pad, pre_lrelu_slope=slope), got)
+    finally:
+        e2.close()
+    monkeypatch.setenv("EV_NO_SK_BALANCE", "1")
+    e3 = Engine(0)
+    try:
+        _close(e3.op_conv1d(x.cuda(), w, b, padding=pad, pre_lrelu_slope=slope), got, what="one tile per workgroup vs balanced")
+        assert e3.sk_stats()[0] == 0
+    finally:
+        e3.close()
+
+
 @pytest.mark.parametrize("B,Cin,T,Cout,K,s,p", [(2, 512, 37, 256, 16, 8, 4), (2, 256, 70, 128, 16, 8, 4), (2, 128, 130, 64, 4, 2, 1),
                                                 (3, 64, 257, 32, 4, 2, 1), (2, 256, 66, 256, 4, 2, 1)])
 def test_conv_transpose1d(eng, B, Cin, T, Cout, K, s, p):
