@@ -351,12 +351,12 @@ def config5_record(model, voc, n_utt=32):
                 "min_frames": int(min(frames)), "max_frames": int(max(frames))}, frames
 
     tts.respond("warm up " + emojis[0])
-    warm_texts = [make_text(int(torch.randint(17, 170, (1,), generator=g)), g) for _ in range(n_utt)]    # ~5.1 frames per character
+    warm_texts = [make_text(int(torch.randint(20, 200, (1,), generator=g)), g) for _ in range(n_utt)]    # ~4.3 frames per character
     _, seen = run(warm_texts)                                    # untimed pass: every warm length has now been planned once
     torch.cuda.synchronize()
     warm, _ = run(warm_texts)
     g2 = torch.Generator().manual_seed(987)
-    cold_texts = [make_text(int(torch.randint(17, 170, (1,), generator=g2)), g2) for _ in range(n_utt)]
+    cold_texts = [make_text(int(torch.randint(20, 200, (1,), generator=g2)), g2) for _ in range(n_utt)]
     a0 = model.engine.alloc_count() + voc.engine.alloc_count()
     cold, cold_frames = run(cold_texts)
     cold["new_lengths"] = int(sum(1 for f in cold_frames if f not in set(seen)))

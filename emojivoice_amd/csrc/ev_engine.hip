@@ -36,6 +36,7 @@ struct ConvLayer {
     float* bias = nullptr;    // [Cout] (stacked / phase-replicated as needed) or null
     int2* taplist[3] = {nullptr, nullptr, nullptr};   // for BM = 128, 64, 32: [mtiles][EV_MAX_TAPS] {tap, row offset} (one shared row when dense)
     int* nact[3] = {nullptr, nullptr, nullptr};       // per-tile active tap count (null when dense)
+    unsigned char nact64[16] = {0};                   // host copy of the BM = 64 counts of the first 16 M tiles (unit weights of the balanced build)
     bool sparse_taps = false;
     int kstack_mt = 0, kstack_tap = 0;      // sparse_taps of the stacked [k-tap conv | 1x1 conv] kind: 32-channel tiles >= kstack_mt carry only tap kstack_tap
     int ntaps = 0, off[EV_MAX_TAPS] = {0};
@@ -259,6 +260,7 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
             }
             if (dev_upload(h, tab, &L.taplist[k])) return 1;
             if (dev_upload(h, cnt, &L.nact[k])) return 1;
+            if (k == 1) for (int t = 0; t < mt && t < 16; ++t) L.nact64[t] = (unsigned char)std::min(cnt[t], 15);
         }
     }
     return 0;
@@ -480,13 +482,20 @@ int ensure_sk(ev_handle* h) {
 
 // The balanced persistent build of a conv launch (conv_gemm_bal_kernel): G = wpc x CUs workgroups share the (tile, k-chunk) units.
 template <int BM, int BN, int WM, int WN>
-int launch_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
+int launch_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc, unsigned long long wtab = 0) {
     if (ensure_sk(h)) return 1;
     const int nchunks = p.Kpad / EV_BK;
     const long U = (long)p.mtiles * p.ntiles * nchunks;
     const int G = wpc * h->ncu;
     p.sk.ctrl = h->sk_ctrl; p.sk.flags = h->sk_ctrl + 16; p.sk.part = h->sk_part; p.sk.part_floats = EV_SK_PART_FLOATS;
     p.sk.q = (int)(U / G); p.sk.r = (int)(U % G); p.sk.spin_limit = h->sk_spin;
+    if (wtab) {            // weighted positions (stacked layers): a unit of M tile mt weighs its tap count
+        int wsum = 0;
+        for (int t = 0; t < p.mtiles; ++t) wsum += (int)((wtab >> (4 * t)) & 15ull);
+        const long P = (long)p.ntiles * nchunks * wsum;
+        p.sk.wsum = wsum; p.sk.wtab = wtab; p.sk.mtiles = p.mtiles; p.sk.nchunks = nchunks;
+        p.sk.q = (int)(P / G); p.sk.r = (int)(P % G);
+    }
     const size_t xs = (size_t)(BN + ((lo.halo + 7) & ~7)) * 36;
     constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4);
     size_t smem = (xs > es ? xs : es) * sizeof(float);
@@ -501,7 +510,17 @@ int launch_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
 // a hand-off slot.
 inline bool bal_ok(const ev_handle* h, const ConvLayer& L, const ConvParams& p, long nwg, int wpc) {
     static const bool off = getenv("EV_NO_CONV_BALANCE") != nullptr;
-    return !off && h->sk_balance && h->ncu > 0 && !L.sparse_taps && lean_ok(p) && p.act != ACT_SNAKE && !p.dbg && !p.stamps && !p.gn_part &&
+    // stacked layers (M tiles of unequal cost) keep one tile per workgroup unless EV_CONV_BALANCE_W=1: measured at batch 64
+    // (tools/shape_profile.py) the weighted balanced grid is 3 % SLOWER on them (256 -> 512: 3.13 -> 3.24 ms, 512 -> 512: 1.88 -> 1.94):
+    // 2080 tiles of mixed weight already even out over the CUs, the hand-offs do not pay
+    static const bool no_w = getenv("EV_CONV_BALANCE_W") == nullptr;
+    if (L.sparse_taps) {   // M tiles of unequal cost: weighted units (64-channel tiling only), every tile with at least one tap
+        if (no_w || p.mtiles > 16 || !L.nact[1]) return false;
+        long wsum = 0;
+        for (int t = 0; t < p.mtiles; ++t) { if (L.nact64[t] < 1) return false; wsum += L.nact64[t]; }
+        if ((nwg / p.mtiles) * (p.Kpad / EV_BK) * wsum < 16L * wpc * h->ncu) return false;   // every workgroup several units (none empty)
+    }
+    return !off && h->sk_balance && h->ncu > 0 && lean_ok(p) && p.act != ACT_SNAKE && !p.dbg && !p.stamps && !p.gn_part &&
            nwg >= h->ncu && nwg < 4L * wpc * h->ncu && wpc * h->ncu <= EV_SK_MAXWG && (long)nwg * (p.Kpad / EV_BK) >= (long)wpc * h->ncu;
 }
 
@@ -670,7 +689,12 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         } else launch_sk<1>(p, h->stream, lo);
     } else if (cfg == 6) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        if (lo.kb == 1 && bal_ok(h, L, p, (long)p.mtiles * p.ntiles, 4)) { if (launch_bal<64, 64, 2, 2>(h, p, lo, 4)) return 1; cfg = 56; }
+        if (lo.kb == 1 && bal_ok(h, L, p, (long)p.mtiles * p.ntiles, 4)) {
+            unsigned long long wtab = 0;
+            if (L.sparse_taps) for (int t = 0; t < p.mtiles; ++t) wtab |= (unsigned long long)L.nact64[t] << (4 * t);
+            if (launch_bal<64, 64, 2, 2>(h, p, lo, 4, wtab)) return 1;
+            cfg = L.sparse_taps ? 57 : 56;
+        }
         else launch_cfg<64, 64, 2, 2>(p, h->stream, lo);
     } else if (cfg == 10 && !L.sparse_taps && L.Mpad % 128 == 0) {   // 128 x 192: less halo per MFMA for the wide-halo layers at Cout = 128
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = 0;

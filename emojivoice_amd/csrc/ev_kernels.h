@@ -41,6 +41,10 @@ struct SkCtl {
     int q, r;            // units per workgroup: start(x) = x * q + min(x, r)
     int spin_limit;      // polls before an owner gives up waiting
     int lds_word;        // conv_gemm_bal_kernel: byte offset of the sk_wait word in dynamic LDS
+    // conv_gemm_bal_kernel, layers whose M tiles differ in cost (a 3-tap conv stacked over a 1x1 conv: half of the M tiles carry one
+    // tap): the workgroups share WEIGHTED positions — a unit of M tile mt weighs wtab[mt] (its taps, 4 bits each, up to 16 M tiles) —
+    // and a position is rounded down to the unit that contains it.  wsum = sum of the weights over the M tiles (0 = all units equal).
+    int wsum; int mtiles; int nchunks; unsigned long long wtab;
 };
 
 struct ConvParams {
@@ -424,7 +428,23 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
 // the bits the contributor would have delivered — slower, never different, never a hang.
 // ---------------------------------------------------------------------------
 typedef __attribute__((address_space(1))) unsigned ev_gu32;
-__device__ __forceinline__ int sk_start(const SkCtl& c, int x) { return x * c.q + (x < c.r ? x : c.r); }
+__device__ __forceinline__ int sk_start(const SkCtl& c, int x) {
+    const int pos = x * c.q + (x < c.r ? x : c.r);
+    if (c.wsum == 0) return pos;
+    // weighted: position -> unit.  Units are ordered (n tile, M tile, chunk); one n tile spans nchunks * wsum positions
+    const int per_nt = c.nchunks * c.wsum;
+    const int nt = pos / per_nt;
+    int rem = pos - nt * per_nt, mt = 0;
+    for (; mt < c.mtiles - 1; ++mt) {
+        const int span = c.nchunks * (int)((c.wtab >> (4 * mt)) & 15ull);
+        if (rem < span) break;
+        rem -= span;
+    }
+    const int w = (int)((c.wtab >> (4 * mt)) & 15ull);
+    int ch = rem / w;
+    if (ch > c.nchunks) ch = c.nchunks;                    // (pos == total: the end sentinel lands on the first unit of the next n tile)
+    return (nt * c.mtiles + mt) * c.nchunks + ch;
+}
 __device__ __forceinline__ unsigned sk_tag(const SkCtl& c) {
     return c.ctrl ? (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load((ev_gu32*)c.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + 1u : 0u;
 }

@@ -7,6 +7,7 @@ package is missing.
 """
 from __future__ import annotations
 
+import bisect
 from typing import Tuple
 
 EMOJI_MAPPING = {  # feel_me.py:84-96 (female voice set of the Paige checkpoint)
@@ -62,8 +63,14 @@ _VS16, _ZWJ, _KEYCAP = 0xFE0F, 0x200D, 0x20E3
 _KEYCAP_BASE = frozenset("0123456789#*")
 
 
+_LOWS = [lo for lo, _ in _EMOJI_RANGES]          # (ascending: the table is sorted by code point)
+
+
 def _is_base(o: int) -> bool:
-    return any(lo <= o <= hi for lo, hi in _EMOJI_RANGES)
+    if o < 0xA9:                                  # ASCII and Latin-1 below the copyright sign: the common case of an LLM response
+        return False
+    i = bisect.bisect_right(_LOWS, o) - 1
+    return i >= 0 and o <= _EMOJI_RANGES[i][1]
 
 
 def _is_emoji_fallback(ch: str) -> bool:

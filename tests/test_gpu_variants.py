@@ -1,6 +1,7 @@
 """The kernel A/B switches (tile configuration, two-chunk staging, generic instead of lean epilogue, unfused resblock pairs,
 fused LayerNorm + QKV / feed-forward kernels forced on at a small batch or switched off, split-key attention switched off,
-the three ResBlock1 chains of an MRF level on one stream instead of three, the workspace zeroed whole instead of its pad rows)
+the three ResBlock1 chains of an MRF level on one stream instead of three, the workspace zeroed whole instead of its pad rows,
+the balanced persistent grids and the fused attention + projection kernel at batch 64)
 must not change results: every build accumulates in the same (chunk, tap, k-group) order, so the variants agree with the
 default path to fp32 rounding of the epilogue (bias added before vs after the K loop).  The switches are read once per
 process, hence one child process per variant."""
@@ -24,13 +25,14 @@ dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(7)
 B, T = 3, 44
 if len(sys.argv) > 2 and sys.argv[2] == "b1": B, T = 1, 100
+if len(sys.argv) > 2 and sys.argv[2] == "b64": B, T = 64, 260
 m = MatchaTTS(W.synthetic_matcha_state(), device=dev)
 voc = Generator(AttrDict(v1)).to(dev); voc.load_state_dict(W.synthetic_hifigan_state())
 mu = torch.randn(B, 80, T, generator=g).to(dev); z = (torch.randn(B, 80, T, generator=g) * 0.667).to(dev)
-lengths = torch.tensor([44, 31, 17] if B == 3 else [T], dtype=torch.int32).to(dev)
-spk = m._sd["spk_emb.weight"][torch.tensor([1, 5, 9][:B], device=dev)]
-mel = m.engine.cfm_decode(mu, lengths, spk, z, 4, m.mel_std, m.mel_mean)
-wav = voc(mel)
+lengths = torch.tensor([44, 31, 17] if B == 3 else ([T] if B == 1 else [T - (7 * i) %% 90 for i in range(B)]), dtype=torch.int32).to(dev)
+spk = m._sd["spk_emb.weight"][(torch.arange(B, device=dev) * 4 + 1) %% 109]
+mel = m.engine.cfm_decode(mu, lengths, spk, z, 4 if B < 64 else 2, m.mel_std, m.mel_mean)
+wav = voc(mel if B < 64 else mel[:4])
 torch.save({"mel": mel.cpu(), "wav": wav.cpu()}, sys.argv[1])
 """ % REPO
 
@@ -71,6 +73,26 @@ def test_batch1_variants_agree(tmp_path):
     assert ref["mel"].shape == (1, 80, 100)
     for i, extra in enumerate(B1_VARIANTS):
         got = _run(tmp_path, f"b1_v{i}", extra, "b1")
+        dmel = float((got["mel"] - ref["mel"]).abs().max())
+        dwav = float((got["wav"] - ref["wav"]).abs().max())
+        assert dmel <= 2e-5 and dwav <= 5e-5, (extra, dmel, dwav)
+
+
+# batch 64: the balanced persistent builds (SkCtl in ev_kernels.h: ln_mlp_kernel, conv_gemm_bal_kernel with equal and with weighted
+# units) and the fused attention + projection kernel.  An owner that never waits (EV_SK_SPIN=0) recomputes every contributor's share
+# as a separate partial sum: the SAME bits.  The one-tile-per-workgroup builds differ by the order of partial sums only.
+def test_batch64_balanced_builds(tmp_path):
+    ref = _run(tmp_path, "b64_default", {}, "b64")
+    assert ref["mel"].shape == (64, 80, 260) and float(ref["mel"].abs().max()) > 1e-1
+    import torch
+
+    again = _run(tmp_path, "b64_again", {}, "b64")
+    assert torch.equal(again["mel"], ref["mel"]) and torch.equal(again["wav"], ref["wav"])          # deterministic run to run
+    nowait = _run(tmp_path, "b64_nowait", {"EV_SK_SPIN": "0"}, "b64")
+    assert torch.equal(nowait["mel"], ref["mel"]) and torch.equal(nowait["wav"], ref["wav"])
+    for i, extra in enumerate([{"EV_NO_SK_BALANCE": "1"}, {"EV_NO_CONV_BALANCE": "1"}, {"EV_CONV_BALANCE_W": "1"}, {"EV_FUSE_ATTN": "0"}, {"EV_SK_WGS": "3"},
+                               {"EV_BAL5": "192"}, {"EV_BAL5": "64"}]):
+        got = _run(tmp_path, f"b64_v{i}", extra, "b64")
         dmel = float((got["mel"] - ref["mel"]).abs().max())
         dwav = float((got["wav"] - ref["wav"]).abs().max())
         assert dmel <= 2e-5 and dwav <= 5e-5, (extra, dmel, dwav)
