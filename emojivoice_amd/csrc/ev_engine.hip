@@ -807,7 +807,19 @@ int launch_gn(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const fl
         hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(h->gn_stats_tiles, 8), dim3(256), 0, h->stream, p, part, h->gn_stats_tiles);
     // small batches: 1024 threads per (utterance, group) shorten the per-workgroup latency chain (8 workgroups at B = 1)
     else if (g.nrows / g.S < 32) hipLaunchKernelGGL(groupnorm_mish_kernel<1024>, dim3(g.nrows / g.S, 8), dim3(1024), 0, h->stream, p);
-    else hipLaunchKernelGGL(groupnorm_mish_kernel<256>, dim3(g.nrows / g.S, 8), dim3(256), 0, h->stream, p);
+    else {
+        // 512 threads per (utterance, group) slab: the workgroup's serial chain (load, two reductions, apply) is half as long as
+        // with 256 (tools/decode_time.py, batch 64: 41.07 -> 40.60 ms per decode with 512, 40.94 with 1024); EV_GN_THREADS=<256|512|1024>
+        // for A/B runs
+        static const int gnt = getenv("EV_GN_THREADS") ? atoi(getenv("EV_GN_THREADS")) : 512;
+        // EV_GN_PRE=1: residual / mask rows requested together with the slab (one memory round trip less per workgroup) — measured
+        // SLOWER (40.8 -> 41.3 ms): 141 registers leave one 512-thread workgroup per CU where the plain build keeps two
+        static const bool gnpre = getenv("EV_GN_PRE") ? atoi(getenv("EV_GN_PRE")) != 0 : false;
+        if (gnt == 512 && gnpre) hipLaunchKernelGGL((groupnorm_mish_kernel<512, true>), dim3(g.nrows / g.S, 8), dim3(512), 0, h->stream, p);
+        else if (gnt == 512) hipLaunchKernelGGL(groupnorm_mish_kernel<512>, dim3(g.nrows / g.S, 8), dim3(512), 0, h->stream, p);
+        else if (gnt == 1024) hipLaunchKernelGGL(groupnorm_mish_kernel<1024>, dim3(g.nrows / g.S, 8), dim3(1024), 0, h->stream, p);
+        else hipLaunchKernelGGL(groupnorm_mish_kernel<256>, dim3(g.nrows / g.S, 8), dim3(256), 0, h->stream, p);
+    }
     HIPCHK(h, hipGetLastError());
     return 0;
 }

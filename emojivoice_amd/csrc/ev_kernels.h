@@ -1665,7 +1665,7 @@ struct GNParams {
     int S, P, T, CG; int mode; float eps;
 };
 
-template <int NTHR>
+template <int NTHR, bool PRE = false>
 __global__ __launch_bounds__(NTHR) void groupnorm_mish_kernel(const GNParams p) {
     __shared__ float red[NTHR / 64];
     const int b = blockIdx.x, g = blockIdx.y;
@@ -1679,10 +1679,17 @@ __global__ __launch_bounds__(NTHR) void groupnorm_mish_kernel(const GNParams p) 
     // The (T x 32-channel) slab of one (utterance, group) is read from HBM/L2 ONCE and kept in registers when it fits
     // (T <= GN_REG_PASSES * rows-per-pass: 768 frames with 256 threads, 1024 with the 1024-thread build used for small batches); longer utterances fall
     // back to three passes over the (L2-resident) slab.
-    constexpr int GN_REG_PASSES = NTHR == 256 ? 24 : 8;
+    constexpr int GN_REG_PASSES = NTHR == 256 ? 24 : (NTHR == 512 ? 12 : 8);
     const bool in_regs = p.T <= GN_REG_PASSES * rpp;
     f32x4 keep[GN_REG_PASSES];
 
+    // The residual rows (mode 2) and the frame mask do not depend on the statistics: on the register-resident path they are requested
+    // together with the slab, so that the apply phase after the two reductions is arithmetic and stores only (one memory round trip
+    // less on every workgroup's critical chain).  An A/B build (EV_GN_PRE=1): measured slower at batch 64 — its 141 registers halve the
+    // workgroups per CU — and not the default.
+    // (PRE: only with >= 512 threads — the 256-thread build keeps 24 slab passes and has no registers left for it)
+    f32x4 rkeep[PRE ? GN_REG_PASSES : 1];
+    float mkeep[PRE ? GN_REG_PASSES : 1];
     float s = 0.f;
     if (in_regs) {
 #pragma unroll
@@ -1691,6 +1698,15 @@ __global__ __launch_bounds__(NTHR) void groupnorm_mish_kernel(const GNParams p) 
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (t < p.T) v = *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase);
             keep[q] = v;
+            if constexpr (PRE) {
+                f32x4 r = {0.f, 0.f, 0.f, 0.f};
+                float m = 0.f;
+                if (t < p.T) {
+                    m = p.rowmask[rowbase + t];
+                    if (p.mode == 2) r = *(const f32x4*)(p.R + (rowbase + t) * p.ldr + cbase);
+                }
+                rkeep[q] = r; mkeep[q] = m;
+            }
             s += (v[0] + v[1]) + (v[2] + v[3]);
         }
     } else {
@@ -1746,7 +1762,23 @@ __global__ __launch_bounds__(NTHR) void groupnorm_mish_kernel(const GNParams p) 
 #pragma unroll
         for (int q = 0; q < GN_REG_PASSES; ++q) {
             const int t = r0 + q * rpp;
-            if (t < p.T) apply(t, keep[q]);
+            if constexpr (PRE) {
+                if (t < p.T) {
+                    const float m = mkeep[q];
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float y = (keep[q][e] - mean) * rstd * ga[e] + be[e];
+                        y = ev_mish(y) * m;
+                        if (p.mode == 1) y = (y + te[e]) * m;
+                        o[e] = y;
+                    }
+                    if (p.mode == 2) { o[0] += rkeep[q][0]; o[1] += rkeep[q][1]; o[2] += rkeep[q][2]; o[3] += rkeep[q][3]; }
+                    *(f32x4*)(p.Y + (rowbase + t) * p.ldy + cbase) = o;
+                }
+            } else {
+                if (t < p.T) apply(t, keep[q]);
+            }
         }
     } else {
         for (int t = r0; t < p.T; t += rpp) apply(t, *(const f32x4*)(p.X + (rowbase + t) * p.ldx + cbase));
