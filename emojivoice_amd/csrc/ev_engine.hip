@@ -959,7 +959,41 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
     ensure_dyn_smem<attn_out_kernel>(smem, h->device);
-    hipLaunchKernelGGL(attn_out_kernel, dim3((unsigned)(p.nq * B)), dim3(256), smem, h->stream, p);
+    static const char* stamp_file = getenv("EV_ATTN_STAMPS");      // diagnostic: per-workgroup phase stamps of the first launches, appended to this file
+    static int stamped = 0;
+    const int nwg = p.nq * B;
+    if (stamp_file && *stamp_file && stamped < 8 && B >= 32) {
+        unsigned long long* d = nullptr;
+        HIPCHK(h, hipMalloc((void**)&d, (size_t)nwg * 6 * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemsetAsync(d, 0, (size_t)nwg * 6 * sizeof(unsigned long long), h->stream));
+        p.stamps = d;
+        hipLaunchKernelGGL(attn_out_kernel, dim3((unsigned)nwg), dim3(256), smem, h->stream, p);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<unsigned long long> st((size_t)nwg * 6);
+        HIPCHK(h, hipMemcpy(st.data(), d, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        hipFree(d);
+        unsigned long long t0 = ~0ull;
+        for (int i = 0; i < nwg; ++i) t0 = std::min(t0, st[(size_t)i * 6]);
+        if (FILE* f = fopen(stamp_file, "a")) {
+            const char* names[6] = {"start", "first key tile", "key loop done", "merged", "projection done", "end"};
+            fprintf(f, "## attn_out_kernel T=%d B=%d: %d workgroups; us since the first workgroup started (100 MHz s_memrealtime)\n", g.T, B, nwg);
+            for (int k = 0; k < 6; ++k) {
+                std::vector<double> v(nwg);
+                for (int i = 0; i < nwg; ++i) v[i] = (double)(st[(size_t)i * 6 + k] - t0) / 100.0;
+                std::sort(v.begin(), v.end());
+                fprintf(f, "  %-16s min %7.1f  p10 %7.1f  p50 %7.1f  p90 %7.1f  max %7.1f\n", names[k], v[0], v[nwg / 10], v[nwg / 2], v[(size_t)nwg * 9 / 10], v[nwg - 1]);
+            }
+            for (int k = 0; k < 5; ++k) {              // per-workgroup phase durations
+                std::vector<double> v(nwg);
+                for (int i = 0; i < nwg; ++i) v[i] = (double)(st[(size_t)i * 6 + k + 1] - st[(size_t)i * 6 + k]) / 100.0;
+                std::sort(v.begin(), v.end());
+                fprintf(f, "  phase %-16s -> %-16s p10 %6.1f  p50 %6.1f  p90 %6.1f us\n", names[k], names[k + 1], v[nwg / 10], v[nwg / 2], v[(size_t)nwg * 9 / 10]);
+            }
+            fclose(f);
+        }
+        ++stamped;
+        p.stamps = nullptr;
+    } else hipLaunchKernelGGL(attn_out_kernel, dim3((unsigned)nwg), dim3(256), smem, h->stream, p);
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
         HIPCHK(h, hipEventRecord(e1, h->stream));

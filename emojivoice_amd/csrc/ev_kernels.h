@@ -2386,6 +2386,7 @@ struct AttnOutParams {
     ConvParams ep;              // epilogue view: Y = R = the hidden rows (in place), ldy = ldr, Cout = 256, bias, nrows / S / P / T
     int S, P, T, B, nq;         // nq = ceil(T / 32) query tiles per utterance
     float scale; int xcd_map;   // xcd_map: B % 8 == 0 -> the tiles of an utterance share an XCD (its K / V stay in that XCD's L2)
+    unsigned long long* stamps; // diagnostic (EV_ATTN_STAMPS): six s_memrealtime stamps per workgroup, or null
 };
 
 #define AO_LDK 68
@@ -2404,6 +2405,8 @@ __global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p)
     }
     const int q0 = qt * 32;
     const unsigned rowbase = (unsigned)b * p.S + p.P;
+    auto stamp = [&](int k) { if (p.stamps && tid == 0) p.stamps[6 * blockIdx.x + k] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
     float* Ks = smem + wave * (2 * 32 * AO_LDK);       // this wave's private K tile [32 keys][64 + 4]
     float* Vs = Ks + 32 * AO_LDK;                      // ... and V tile
     const __amdgpu_buffer_rsrc_t rQ = ev_rsrc(p.QKV), rM = ev_rsrc(p.rowmask), rW = ev_rsrc(p.Wout);
@@ -2444,6 +2447,7 @@ __global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p)
     float mrun = -1e30f, lrun = 0.f;
     if (kt0 < kt1) kv_issue(kt0);
     for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt == kt0 + 1) stamp(1);                   // (first key tile done)
         // publish the prefetched tile to this wave's LDS (the wave's LDS operations execute in order: no barrier, no other reader)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -2489,6 +2493,7 @@ __global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p)
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, s[r], o1, 0, 0, 0);
         }
     }
+    stamp(2);
     // ---- first weight fragments of the projection (this wave: output channels 64 wave .. +63 = row tiles 2 wave, 2 wave + 1; 16
     // k-groups), into the staging registers: they land while the key halves are merged
     const unsigned wlane = (unsigned)lane * 16u;
@@ -2535,6 +2540,7 @@ __global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p)
         }
     }
     ev_lds_barrier();
+    stamp(3);
     // ---- projection: Y^T[256][32] = Wout . O^T, K = 128 = 16 k-groups; bias preloaded into the accumulators (lean epilogue convention)
     f32x16 acc[2][1];
 #pragma unroll
@@ -2558,8 +2564,10 @@ __global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p)
         }
         if (kg < 8) { kr[kg] = ldW(0, kg + 8); vr[kg] = ldW(1, kg + 8); }
     }
+    stamp(4);
     // ---- + residual rows, store (rows of THIS utterance only: a tile's tail rows may belong to the next one)
     conv_epilogue_lean<2, 1, 1>(p.ep, acc, smem + wave * (32 * 68), wave * 64, (int)rowbase + q0, lane, (int)rowbase, (int)rowbase + p.T);
+    stamp(5);
 }
 
 // ---------------------------------------------------------------------------
