@@ -86,12 +86,10 @@ def test_batch64_balanced_builds(tmp_path):
     assert ref["mel"].shape == (64, 80, 260) and float(ref["mel"].abs().max()) > 1e-1
     import torch
 
-    again = _run(tmp_path, "b64_again", {}, "b64")
-    assert torch.equal(again["mel"], ref["mel"]) and torch.equal(again["wav"], ref["wav"])          # deterministic run to run
     nowait = _run(tmp_path, "b64_nowait", {"EV_SK_SPIN": "0"}, "b64")
     assert torch.equal(nowait["mel"], ref["mel"]) and torch.equal(nowait["wav"], ref["wav"])
-    for i, extra in enumerate([{"EV_NO_SK_BALANCE": "1"}, {"EV_NO_CONV_BALANCE": "1"}, {"EV_CONV_BALANCE_W": "1"}, {"EV_FUSE_ATTN": "0"}, {"EV_SK_WGS": "3"},
-                               {"EV_BAL5": "192"}, {"EV_BAL5": "64"}]):
+    # (run-to-run equality of the default build is covered in-process by tests/test_gpu_ops.py; every switch here costs a batch-64 child)
+    for i, extra in enumerate([{"EV_NO_SK_BALANCE": "1"}, {"EV_CONV_BALANCE_W": "1", "EV_BAL5": "64"}, {"EV_FUSE_ATTN": "0", "EV_SK_WGS": "3"}]):
         got = _run(tmp_path, f"b64_v{i}", extra, "b64")
         dmel = float((got["mel"] - ref["mel"]).abs().max())
         dwav = float((got["wav"] - ref["wav"]).abs().max())
