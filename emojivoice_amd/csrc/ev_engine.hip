@@ -944,6 +944,11 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
     const int B = g.nrows / g.S;
     p.QKV = QKV; p.ld = ld; p.rowmask = rowmask; p.Wout = Lo.W; p.S = g.S; p.P = g.P; p.T = g.T; p.B = B; p.nq = (g.T + 31) / 32; p.scale = 0.125f;
     p.xcd_map = (B % 8 == 0) ? 1 : 0;
+    {   // a short last query tile (<= AO_TAILQ queries) goes to one small 4 x 4-block workgroup per utterance, dispatched first
+        static const bool no_tail = getenv("EV_ATTN_NO_TAIL") != nullptr;
+        const int last = g.T - 32 * (p.nq - 1);
+        if (!no_tail && p.nq >= 2 && last <= AO_TAILQ) { p.ntail = last; p.nq -= 1; }
+    }
     ConvParams& e = p.ep;
     e.Y = Hid; e.ldy = ldh; e.Cout = Lo.Cout; e.bias = Lo.bias; e.R = Hid; e.ldr = ldh; e.osplit_log2 = 31; e.isplit_log2 = 31; e.mmul = 1; e.scale = 1.f;
     e.nrows = g.nrows; e.S = g.S; e.P = g.P; e.T = g.T;
@@ -961,7 +966,7 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
     ensure_dyn_smem<attn_out_kernel>(smem, h->device);
     static const char* stamp_file = getenv("EV_ATTN_STAMPS");      // diagnostic: per-workgroup phase stamps of the first launches, appended to this file
     static int stamped = 0;
-    const int nwg = p.nq * B;
+    const int nwg = p.nq * B + (p.ntail > 0 ? B : 0);
     if (stamp_file && *stamp_file && stamped < 8 && B >= 32) {
         unsigned long long* d = nullptr;
         HIPCHK(h, hipMalloc((void**)&d, (size_t)nwg * 6 * sizeof(unsigned long long)));
@@ -988,6 +993,12 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
                 for (int i = 0; i < nwg; ++i) v[i] = (double)(st[(size_t)i * 6 + k + 1] - st[(size_t)i * 6 + k]) / 100.0;
                 std::sort(v.begin(), v.end());
                 fprintf(f, "  phase %-16s -> %-16s p10 %6.1f  p50 %6.1f  p90 %6.1f us\n", names[k], names[k + 1], v[nwg / 10], v[nwg / 2], v[(size_t)nwg * 9 / 10]);
+            }
+            if (p.ntail > 0) {                          // the short-tile workgroups (block ids 0 .. B-1) on their own
+                std::vector<double> v0(B), v1(B);
+                for (int i = 0; i < B; ++i) { v0[i] = (double)(st[(size_t)i * 6] - t0) / 100.0; v1[i] = (double)(st[(size_t)i * 6 + 5] - t0) / 100.0; }
+                std::sort(v0.begin(), v0.end()); std::sort(v1.begin(), v1.end());
+                fprintf(f, "  short last tile (%d queries, 4 x 4 blocks): start p50 %6.1f max %6.1f   end p50 %6.1f max %6.1f us\n", p.ntail, v0[B / 2], v0[B - 1], v1[B / 2], v1[B - 1]);
             }
             fclose(f);
         }

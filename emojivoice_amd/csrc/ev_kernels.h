@@ -2384,13 +2384,180 @@ struct AttnOutParams {
     const float* rowmask;
     const float* Wout;          // fragment order [256/32][128/8][64 lanes][4]
     ConvParams ep;              // epilogue view: Y = R = the hidden rows (in place), ldy = ldr, Cout = 256, bias, nrows / S / P / T
-    int S, P, T, B, nq;         // nq = ceil(T / 32) query tiles per utterance
+    int S, P, T, B, nq;         // nq = query tiles per utterance that the 32 x 32 workgroups take (all of them, or all but a short last one)
+    int ntail;                  // > 0: the last tile holds only ntail (<= 4) queries and is computed by one small workgroup per utterance on
+                                // 4 x 4 MFMA blocks (blocks 0 .. B-1 of the grid, dispatched first): see attn_tail_path
     float scale; int xcd_map;   // xcd_map: B % 8 == 0 -> the tiles of an utterance share an XCD (its K / V stay in that XCD's L2)
     unsigned long long* stamps; // diagnostic (EV_ATTN_STAMPS): six s_memrealtime stamps per workgroup, or null
 };
 
 #define AO_LDK 68
 #define AO_OLD 132
+#define AO_TAILQ 4             // most queries a short last tile may hold to take the 4 x 4 path
+// The short last query tile of an utterance (T = 516 = 16 x 32 + 4 queries, T / 2 = 258 = 8 x 32 + 2) as a workgroup of its own costs a
+// full one — 32-column MFMA tiles for 2-4 queries — and pushed every launch into one more round of workgroups: per-workgroup stamps
+// (profiles/r03_attn_workgroup_stamps.txt) show 64 of the 576 / 1088 workgroups starting when all others have finished, 40 % of the
+// T / 2 launch.  Here those queries run on v_mfma_f32_4x4x1_16b_f32 — sixteen independent 4 x 4 outer products per instruction at the
+// full fp32 matrix rate, so four query columns waste nothing — in one workgroup per utterance that is dispatched first and gone after
+// a few microseconds.  (The same on the VECTOR ALUs was tried first: beside co-resident waves that stream MFMAs its dependent VALU
+// chains got almost no issue slots and the 64 workgroups finished last.)  Layout of the instruction, confirmed with exact integer
+// data (tools/mfma4x4_probe.hip): lane l = 4 block + x holds A[block][i = x] and B[block][j = x]; D register r of lane l is
+// D[block][i = r][j = x].
+//   scores:  block = (key group kg of 4 keys, dim half dh);  A = K[4 kg + x][32 dh + s], B = Q[query x][32 dh + s], s = 0..31  ->
+//            D reg i = half score of key 4 kg + i for query x; the two dim halves are lane ^ 4
+//   P . V:   block = 4 dims;  A = P[query x][key] (every block the same: gathered with ds_bpermute from the score layout),
+//            B = V[key][lane]  ->  D reg i = O[query i][dim lane]
+// Same (head, key half) waves, wave-private K / V tiles, merge of the key halves and projection (one output channel per thread here).
+__device__ __forceinline__ void attn_tail_path(const AttnOutParams& p, int b, float* smem, int tid, int lane, int wave) {
+    const int x = lane & 3, dh = (lane >> 2) & 1, kg = lane >> 3, li = lane & 31, h = wave & 1, kh = wave >> 1;
+    const int NT = p.ntail;
+    const int q0 = p.nq * 32;
+    const unsigned rowbase = (unsigned)b * p.S + p.P;
+    float* Ks = smem + wave * (2 * 32 * AO_LDK);
+    float* Vs = Ks + 32 * AO_LDK;
+    const __amdgpu_buffer_rsrc_t rQ = ev_rsrc(p.QKV), rM = ev_rsrc(p.rowmask), rW = ev_rsrc(p.Wout);
+    const float L2E = 1.44269504088896340736f;
+    const unsigned ldb = (unsigned)p.ld * 4u;
+    // this lane's query (x) and dim half (dh), pre-scaled into the log2 domain; queries beyond the tile's are zero
+    f32x4 qv[8];
+    {
+        const bool ok = x < NT;
+        const unsigned off = (rowbase + (unsigned)(ok ? q0 + x : 0)) * ldb + (unsigned)(h * 64 + 32 * dh) * 4u;
+        const float qs = ok ? p.scale * L2E : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) qv[i] = ev_bload4(rQ, off + (unsigned)(4 * i) * 4u, 0) * qs;
+    }
+    const int nkt = (p.T + 31) / 32, nh0 = (nkt + 1) / 2;
+    const int kt0 = kh ? nh0 : 0, kt1 = kh ? nkt : nh0;
+    f32x4 kr[8], vr[8];
+    f32x4 mk4 = {0.f, 0.f, 0.f, 0.f};                  // masks of this lane's four keys (log2 domain)
+    const int srow = lane >> 4, sc4 = (lane & 15) * 4;
+    const unsigned kcol = (unsigned)(128 + h * 64 + sc4) * 4u, vcol = (unsigned)(256 + h * 64 + sc4) * 4u;
+    auto kv_issue = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tk = kt * 32 + 4 * j + srow;
+            const unsigned ro = (rowbase + (unsigned)(tk < p.T ? tk : p.T - 1)) * ldb;
+            kr[j] = ev_bload4(rQ, ro + kcol, 0);
+            vr[j] = ev_bload4(rQ, ro + vcol, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int tm = kt * 32 + 4 * kg + i;
+            const float m = ev_bload1(rM, (rowbase + (unsigned)(tm < p.T ? tm : p.T - 1)) * 4u, 0);
+            mk4[i] = tm < p.T ? m * L2E : -1e30f;
+        }
+    };
+    f32x4 o = {0.f, 0.f, 0.f, 0.f}, o2 = o;            // o[i] (+ o2[i]) = O[query i][dim lane], un-normalised
+    float mrun = -1e30f, lrun = 0.f;                   // running max / sum of THIS lane's query x
+    if (kt0 < kt1) kv_issue(kt0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            *(f32x4*)(Ks + (4 * j + srow) * AO_LDK + sc4) = kr[j];
+            *(f32x4*)(Vs + (4 * j + srow) * AO_LDK + sc4) = vr[j];
+        }
+        const f32x4 mkey = mk4;
+        kv_issue(kt + 1 < kt1 ? kt + 1 : kt);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sc2 = sc;
+        f32x4 k4[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) k4[i] = *(const f32x4*)(Ks + (4 * kg + x) * AO_LDK + 32 * dh + 4 * i);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            sc = __builtin_amdgcn_mfma_f32_4x4x1f32(k4[i][0], qv[i][0], sc, 0, 0, 0);
+            sc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(k4[i][1], qv[i][1], sc2, 0, 0, 0);
+            sc = __builtin_amdgcn_mfma_f32_4x4x1f32(k4[i][2], qv[i][2], sc, 0, 0, 0);
+            sc2 = __builtin_amdgcn_mfma_f32_4x4x1f32(k4[i][3], qv[i][3], sc2, 0, 0, 0);
+        }
+        sc += sc2;
+        float mx = -1e30f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[i] = sc[i] + __shfl_xor(sc[i], 4, 64) + mkey[i]; mx = fmaxf(mx, sc[i]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 8, 64)); mx = fmaxf(mx, __shfl_xor(mx, 16, 64)); mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[i] = __builtin_amdgcn_exp2f(sc[i] - mnew); ps += sc[i]; }
+        ps += __shfl_xor(ps, 8, 64); ps += __shfl_xor(ps, 16, 64); ps += __shfl_xor(ps, 32, 64);
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float ai = __shfl(alpha, i, 64); o[i] *= ai; o2[i] *= ai; }   // lane i holds query i's alpha (kg = 0, dh = 0, x = i)
+        float pa[32], vb[32];                          // all gathers and reads in flight together, then the MFMAs on two accumulators
+#pragma unroll
+        for (int key = 0; key < 32; ++key) {
+            pa[key] = __shfl(sc[key & 3], ((key >> 2) << 3) | x, 64);          // P[query x][key] from the lane that holds key group key / 4
+            vb[key] = Vs[key * AO_LDK + lane];
+        }
+#pragma unroll
+        for (int key = 0; key < 32; key += 2) {
+            o = __builtin_amdgcn_mfma_f32_4x4x1f32(pa[key], vb[key], o, 0, 0, 0);
+            o2 = __builtin_amdgcn_mfma_f32_4x4x1f32(pa[key + 1], vb[key + 1], o2, 0, 0, 0);
+        }
+    }
+    o += o2;
+    // ---- every lane gets all four queries' (m, l); merge the key halves, normalise, rows into Ot[query][128] (wave 0's dead region)
+    float mq[4], lq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { mq[i] = __shfl(mrun, i, 64); lq[i] = __shfl(lrun, i, 64); }
+    float* Ot = smem;
+    ev_lds_barrier();
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ks[i * 64 + lane] = o[i];
+        if (lane < 4) { Ks[256 + lane] = mq[lane & 3]; Ks[260 + lane] = lq[lane & 3]; }
+    }
+    ev_lds_barrier();
+    if (kh == 0) {
+        const float* Ps = smem + (wave + 2) * (2 * 32 * AO_LDK);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float m1 = Ps[256 + i], l1 = Ps[260 + i], o1 = Ps[i * 64 + lane];
+            const float m = fmaxf(mq[i], m1);
+            const float a0 = __builtin_amdgcn_exp2f(mq[i] - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+            const float den = lq[i] * a0 + l1 * a1;
+            o[i] = den > 0.f ? (o[i] * a0 + o1 * a1) / den : 0.f;
+        }
+    }
+    ev_lds_barrier();                                  // (partner regions read; Ot lies in wave 0's tiles, dead since the first barrier)
+    if (kh == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ot[i * 128 + h * 64 + lane] = o[i];
+    }
+    ev_lds_barrier();
+    // ---- projection + bias + residual: thread c owns output channel c of the tail rows (weights in MFMA-fragment order: element
+    // (row c, k) sits at (((c / 32) * 16 + k / 8) * 64 + (c % 32) + 32 * ((k % 8) / 4)) * 4 + k % 4)
+    (void)li;
+    const int c = tid;
+    float acc[4];
+    const float bc = p.ep.bias ? p.ep.bias[c] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = bc;
+#pragma unroll 4
+    for (int kgp = 0; kgp < 16; ++kgp) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const f32x4 w4 = ev_bload4(rW, (unsigned)((((c >> 5) * 16 + kgp) * 64 + (c & 31) + 32 * hf) * 16), 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 x4 = *(const f32x4*)(Ot + j * 128 + kgp * 8 + hf * 4);
+                acc[j] = fmaf(w4[0], x4[0], acc[j]); acc[j] = fmaf(w4[1], x4[1], acc[j]);
+                acc[j] = fmaf(w4[2], x4[2], acc[j]); acc[j] = fmaf(w4[3], x4[3], acc[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int tq = q0 + j;
+        if (j < NT && tq < p.T) {
+            const size_t off = (size_t)(rowbase + tq) * p.ep.ldy + c;
+            p.ep.Y[off] = acc[j] + p.ep.R[(size_t)(rowbase + tq) * p.ep.ldr + c];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2399,7 +2566,15 @@ __global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p)
     const int h = wave & 1, kh = wave >> 1;
     int b, qt;
     {
-        const int id = blockIdx.x;
+        int id = blockIdx.x;
+        const int ntw = p.ntail > 0 ? p.B : 0;         // the short last tiles first: small 4 x 4-block workgroups (attn_tail_path)
+        if (id < ntw) {
+            if (p.stamps && tid == 0) p.stamps[6 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+            attn_tail_path(p, p.xcd_map ? (id & 7) + 8 * (id >> 3) : id, smem, tid, lane, wave);
+            if (p.stamps && tid == 0) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); for (int k = 1; k < 6; ++k) p.stamps[6 * blockIdx.x + k] = t; }
+            return;
+        }
+        id -= ntw;                                     // (B % 8 == 0 under xcd_map: the XCD of a block id is unchanged)
         if (p.xcd_map) { const int within = id >> 3; qt = within % p.nq; b = (id & 7) + 8 * (within / p.nq); }
         else { b = id / p.nq; qt = id - b * p.nq; }
     }

@@ -151,10 +151,11 @@ def test_attention(eng, B, T, lens):
 
 
 @pytest.mark.parametrize("B,T,lens", [(3, 70, [70, 33, 1]), (2, 516, [516, 400]), (8, 258, [258, 1, 100, 258, 31, 32, 33, 257]), (1, 32, [32]),
-                                      (2, 4, [4, 2]), (64, 132, None)])
+                                      (2, 4, [4, 2]), (64, 132, None), (3, 33, [33, 32, 5]), (5, 67, [67, 66, 65, 64, 1]), (16, 98, None)])
 def test_attn_out_fused(eng, B, T, lens):
     """attn_out_kernel (both heads of the additive-mask attention + the 128 -> 256 output projection + the residual in one launch,
-    transformer.py:262-271) against plain torch fp32 (SDPA with the FLOAT mask added, then Linear with bias, then + hidden)."""
+    transformer.py:262-271) against plain torch fp32 (SDPA with the FLOAT mask added, then Linear with bias, then + hidden).
+    T = 516, 258, 132, 33, 67 and 98 end in a short tile of 4, 2, 4, 1, 3 and 2 queries: the 4 x 4-block path (attn_tail_path)."""
     g = torch.Generator().manual_seed(T * 7 + B)
     heads = 2
     qkv = torch.randn(B, T, 3 * heads * 64, generator=g)
