@@ -33,6 +33,7 @@ struct Geom { int nrows, S, P, T; };  // flattened padded time axis of one resol
 // One convolution / linear layer packed for conv_gemm_kernel.
 struct ConvLayer {
     float* W = nullptr;       // [ntaps][Mpad][Kpad]
+    unsigned short* Wx = nullptr;   // the same weights as three bf16 pieces in conv_split_kernel's fragment order (Kpad % 64 == 0 only)
     float* bias = nullptr;    // [Cout] (stacked / phase-replicated as needed) or null
     int2* taplist[3] = {nullptr, nullptr, nullptr};   // for BM = 128, 64, 32: [mtiles][EV_MAX_TAPS] {tap, row offset} (one shared row when dense)
     int* nact[3] = {nullptr, nullptr, nullptr};       // per-tile active tap count (null when dense)
@@ -214,6 +215,28 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                             Wf[((((size_t)tap * MT32 + mt) * KG8 + kg) * 64 + lane) * 4 + e] = Wh[((size_t)tap * L.Mpad + row) * L.Kpad + k];
                         }
         if (dev_upload(h, Wf, &L.W)) return 1;
+    }
+    if (L.Kpad % EVX_KC == 0) {   // conv_split_kernel: w = w0 + w1 + w2 exactly, each piece the upper half of an fp32 word (bf16);
+        // order [tap][Mpad/32][Kpad/16][piece][lane][8], lane = (row & 31) + 32 * half, element e <-> k = 16 kg + 8 half + e
+        const int MT32 = L.Mpad / 32, KG16 = L.Kpad / 16;
+        std::vector<unsigned short> Wx(Wh.size() * 3);
+        auto bits = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
+        auto fl = [](unsigned u) { float f; memcpy(&f, &u, 4); return f; };
+        for (int tap = 0; tap < L.ntaps; ++tap)
+            for (int mt = 0; mt < MT32; ++mt)
+                for (int kg = 0; kg < KG16; ++kg)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int row = mt * 32 + (lane & 31), k = kg * 16 + 8 * (lane >> 5) + e;
+                            const float w = Wh[((size_t)tap * L.Mpad + row) * L.Kpad + k];
+                            const unsigned p0 = bits(w) & 0xffff0000u;
+                            const float r1 = w - fl(p0);
+                            const unsigned p1 = bits(r1) & 0xffff0000u;
+                            const unsigned p2 = bits(r1 - fl(p1)) & 0xffff0000u;
+                            const size_t base = ((((size_t)tap * MT32 + mt) * KG16 + kg) * 3) * 512 + (size_t)lane * 8 + e;
+                            Wx[base] = (unsigned short)(p0 >> 16); Wx[base + 512] = (unsigned short)(p1 >> 16); Wx[base + 1024] = (unsigned short)(p2 >> 16);
+                        }
+        if (dev_upload(h, Wx, &L.Wx)) return 1;
     }
     if (bias) { if (dev_upload(h, *bias, &L.bias)) return 1; }
     // per-tile compact lists of non-zero taps (polyphase transposed convs have all-zero (phase, tap) slabs)
@@ -438,6 +461,21 @@ void launch_cfg2(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, PF, FULL, LEAN, KB>), dim3(p.mtiles * p.ntiles), dim3(256), smem, st, p);
 }
 
+// conv_split_kernel (fp32 contraction as six bf16 products per element pair): the lean epilogues only
+template <int BM, int BN, int WM, int WN, int TERMS = 6>
+void launch_split(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
+    const size_t xs = (size_t)(BN + ((lo.halo + 7) & ~7)) * EVX_RSB;
+    constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4) * sizeof(float);
+    const size_t smem = xs > es ? xs : es;
+    const dim3 grid(p.mtiles * p.ntiles);
+    if (p.act == ACT_SNAKE) { ensure_dyn_smem<conv_split_kernel<BM, BN, WM, WN, 2, TERMS>>(smem, lo.device); hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, 2, TERMS>), grid, dim3(256), smem, st, p); }
+    else if (lean_acc(p)) { ensure_dyn_smem<conv_split_kernel<BM, BN, WM, WN, 3, TERMS>>(smem, lo.device); hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, 3, TERMS>), grid, dim3(256), smem, st, p); }
+    else { ensure_dyn_smem<conv_split_kernel<BM, BN, WM, WN, 1, TERMS>>(smem, lo.device); hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, 1, TERMS>), grid, dim3(256), smem, st, p); }
+}
+inline bool split_ok(const ConvLayer& L, const ConvParams& p) {
+    return L.Wx && lean_ok(p) && p.isplit_log2 >= 31 && L.Cin % EVX_KC == 0 && L.Cin == L.Kpad && L.Mpad % 128 == 0 && ((size_t)p.bias & 15) == 0;
+}
+
 // small-launch builds (conv_gemm_sk_kernel): 64 x 64 tiles, 16 waves, K split four ways inside the workgroup (TW = 4, KS = 4),
 // or 32 x 32 tiles, 8 waves, K split eight ways (TW = 1, KS = 8) for launches of only a few dozen 64 x 64 tiles
 template <bool FULL, int LEAN, int TW>
@@ -530,7 +568,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     memset(&p, 0, sizeof p);
     h->gn_stats_tiles = 0;
     p.X = X; p.ldx = ldx; p.Cin = L.Cin; p.isplit_log2 = e.isplit_log2; p.isstride = e.isstride;
-    p.W = L.W; p.Mpad = L.Mpad; p.Kpad = L.Kpad; p.bias = L.bias;
+    p.W = L.W; p.Wx = L.Wx; p.Mpad = L.Mpad; p.Kpad = L.Kpad; p.bias = L.bias;
     p.Y = Y; p.ldy = ldy; p.Cout = L.Cout; p.osplit_log2 = e.osplit_log2; p.osstride = e.osstride; p.mmul = e.mmul;
     p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T;
     p.ntaps = L.ntaps; for (int i = 0; i < L.ntaps; ++i) p.off[i] = L.off[i];
@@ -611,6 +649,11 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
             if (g.nrows >= minrows) cfg = c;
         }
     }
+    {   // deep grids of dense-channel layers: the bf16-split build (EV_SPLIT=0: fp32 MFMA everywhere; 3 / 9: products per element pair, A/B)
+        static const int split_terms = getenv("EV_SPLIT") ? atoi(getenv("EV_SPLIT")) : 6;
+        if (split_terms > 0 && (cfg == 0 || cfg == 1 || cfg == 5) && split_ok(L, p) && (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) >= 256L * 2 * 3)
+            cfg = split_terms == 3 ? 43 : split_terms == 9 ? 49 : 40;
+    }
     {   // debugging / test override: EV_FORCE_CFG=<0..3> forces one tile configuration for every conv launch
         static const char* env = getenv("EV_FORCE_CFG");
         if (env && *env) cfg = atoi(env);
@@ -639,7 +682,13 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         static const char* senv = getenv("EV_STAGGER");
         if (senv && *senv) p.stagger_slots = atoi(senv) ? p.stagger_slots : 0;
     }
-    if (cfg == 0) {
+    if ((cfg == 40 || cfg == 43 || cfg == 49) && !split_ok(L, p)) cfg = 0;
+    if (cfg == 40 || cfg == 43 || cfg == 49) {   // 128 x 128 on the bf16 pipe
+        p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        if (cfg == 40) launch_split<128, 128, 2, 2, 6>(p, h->stream, lo);
+        else if (cfg == 43) launch_split<128, 128, 2, 2, 3>(p, h->stream, lo);
+        else launch_split<128, 128, 2, 2, 9>(p, h->stream, lo);
+    } else if (cfg == 0) {
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_cfg<128, 128, 2, 2>(p, h->stream, lo);
     } else if (cfg == 1) {

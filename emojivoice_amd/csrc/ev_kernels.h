@@ -51,6 +51,7 @@ struct ConvParams {
     const float* X; int ldx; int Cin;
     int isplit_log2, isstride;              // input column ci lives at (ci >> isplit_log2)*isstride + (ci & (2^isplit_log2 - 1))
     const float* W; int Mpad; int Kpad;     // fragment order [ntaps][Mpad/32][Kpad/8][64 lanes][4]
+    const void* Wx;                         // conv_split_kernel: the same weights as three bf16 pieces, [ntaps][Mpad/32][Kpad/16][3][64 lanes][8] (null: not packed)
     const float* bias;                      // [Cout] or null
     float* Y; int ldy; int Cout;
     int osplit_log2, osstride;              // same column split for Y / R / Y2 (pair views of a strided slice)
@@ -772,6 +773,208 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     else conv_epilogue<TM, TN, FULL_ACT>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+}
+
+// ---------------------------------------------------------------------------
+// conv_split_kernel: the same implicit GEMM on the bf16 matrix pipe, fp32 in and out.
+//
+// The fp32 MFMA of gfx950 runs at the vector rate (157 TFLOP/s); v_mfma_f32_32x32x16_bf16 runs sixteen times faster and
+// accumulates in fp32.  Every fp32 value is the EXACT sum of three bf16 values (8 + 8 + 8 significand bits: x0 = the upper half
+// of the word, x1 = the upper half of x - x0, x2 = x - x0 - x1), and a bf16 x bf16 product is exact in the fp32 accumulator, so
+//     a . b  =  sum over pieces  a_p . b_q
+// with the six products of weight p + q <= 2 (a0b0, a0b1, a1b0, a0b2, a1b1, a2b0) leaves out only terms below 2^-24 |a b| — the
+// size of ONE fp32 rounding.  Measured (tools/bf16_split_probe.hip, dot products of length 1408 against fp64): fp32 MFMA max
+// 3.1e-6 / rms 6.9e-7 of the result's scale, six products 3.4e-6 / 5.9e-7, nine products the same, three products 8.9e-5: six it
+// is.  Cost: 6 MFMAs of 32 cycles per 16-deep slab against 8 of 64 — 2.67x the rate of the fp32 pipe (probe: 365 TFLOP/s of
+// fp32-equivalent work in a loop fed from LDS and L2, against 153).
+//   weights:     split once by the loader, fragment order [tap][32-row tile][16-deep slab][piece][lane][8 bf16]
+//                (lane = (row & 31) + 32 * half, element e <-> k = 16 slab + 8 half + e): one 16-byte load per lane and piece
+//   activations: split while they are staged: LDS row = three bf16 planes of the 64-channel chunk (+ 16 bytes: an odd multiple of
+//                16 keeps the 16-byte fragment reads conflict-free); a chunk is four slabs, so the fragment ring of the K loop
+//                (four statically named sets, one tap ahead) carries over unchanged from conv_gemm_kernel
+//   epilogue:    the D layout of the 32 x 32 tile is that of the fp32 instruction: conv_epilogue_lean as is
+// ---------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define EVX_KC 64                           // input channels per LDS stage
+#define EVX_RSB (3 * EVX_KC * 2 + 16)       // LDS row stride in bytes (400 = 25 x 16)
+// three bf16 pieces of four fp32 values, packed as the four channels' bf16 in channel order (8 bytes per piece)
+__device__ __forceinline__ void evx_split4(const f32x4 v, uint2& q0, uint2& q1, uint2& q2) {
+    unsigned u[4], w[4];
+    float r[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { u[e] = __float_as_uint(v[e]); r[e] = v[e] - __uint_as_float(u[e] & 0xffff0000u); w[e] = __float_as_uint(r[e]); }
+    q0.x = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u); q0.y = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+    q1.x = __builtin_amdgcn_perm(w[1], w[0], 0x07060302u); q1.y = __builtin_amdgcn_perm(w[3], w[2], 0x07060302u);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) u[e] = __float_as_uint(r[e] - __uint_as_float(w[e] & 0xffff0000u));
+    q2.x = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u); q2.y = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
+}
+template <int TM, int TN, int TERMS>
+__device__ __forceinline__ void evx_mma(f32x16 (&acc)[TM][TN], const f32x4 (&a)[3][TM], const f32x4 (&b)[3][TN]) {
+    // smallest products first; the accumulators of the TM x TN tiles alternate, so consecutive MFMAs are independent
+    constexpr int PA[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}, PB[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 9 - TERMS; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[PA[t]][i]), __builtin_bit_cast(bf16x8, b[PB[t]][j]), acc[i][j], 0, 0, 0);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN, int TERMS = 6>
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvParams p) {
+    constexpr int TM = BM / WAVES_M / 32;
+    constexpr int TN = BN / WAVES_N / 32;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+    static_assert(TERMS == 3 || TERMS == 6 || TERMS == 9, "products per element pair");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;                            // [(BN + halo)][EVX_RSB bytes]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.mtiles * p.ntiles;
+    const int work = ev_xcd_remap(blockIdx.x, nwg);
+    const int mt = work % p.mtiles;
+    const int nt = work / p.mtiles;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+    {   // tiles that contain no storable row (pure padding) do nothing
+        const int t_first = (n0 % p.S) - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - (n0 % p.S) + p.P;
+        if (dist >= BN || n0 + dist >= p.nrows) return;
+    }
+    const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
+    const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        f32x4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bq[g] = z;
+            const int c0 = m0 + wm * (TM * 32) + a * 32 + 8 * g + 4 * lh;
+            if (p.bias && c0 < p.Cout) bq[g] = *(const f32x4*)(p.bias + c0);
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = bq[r >> 2][r & 3];
+    }
+
+    const int xrows = BN + p.halo_lo + p.halo_hi;
+    constexpr int TPR = EVX_KC / 4, RPS = 256 / TPR;   // staging: 16 threads per row, 16 rows per pass
+    const int srow = tid / TPR;
+    const int sc4 = (tid % TPR) * 4;
+    const int nchunks = p.Kpad / EVX_KC;
+    constexpr int XPASS = (BN + EV_HALO) / RPS;
+    constexpr int XG = 6;
+    static_assert(XPASS % XG == 0, "staging batches");
+    const int mt32 = (m0 + wm * (TM * 32)) >> 5;
+    const int KG16 = p.Kpad >> 4;
+    const __amdgpu_buffer_rsrc_t rW = ev_rsrc(p.Wx), rX = ev_rsrc(p.X);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned wbase = (unsigned)(mt32 * KG16) * 3072u;
+    // the tap list carries byte offsets of the fp32 planes ((Mpad/32) (Kpad/8) KiB per tap); a split plane is 1.5 x that
+    auto a_off = [&](int tap_bytes, int kg16) -> unsigned { return (unsigned)tap_bytes + ((unsigned)tap_bytes >> 1) + wbase + (unsigned)kg16 * 3072u; };
+    f32x4 A0[3][TM], A1[3][TM], A2[3][TM], A3[3][TM], B0[3][TN], B1[3][TN];
+    auto ldAp = [&](f32x4 (&dst)[3][TM], unsigned aoff) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) dst[pc][i] = ev_bload4(rW, wlane, aoff + (unsigned)(i * KG16 * 3072 + pc * 1024));
+    };
+    auto ldB = [&](f32x4 (&dst)[3][TN], const char* brow, int slab) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dst[pc][j] = *(const f32x4*)(brow + j * 32 * EVX_RSB + pc * (EVX_KC * 2) + slab * 32);
+    };
+    const char* bbase = Xb + (wn * (TN * 32) + li + p.halo_lo) * EVX_RSB + 16 * lh;
+    const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
+    const int2 tv_first = ev_tap_at(tlv, 0);
+    if (nact > 0) {
+        const unsigned a0 = a_off(tv_first.x, 0);
+        ldAp(A0, a0); ldAp(A1, a0 + 3072u); ldAp(A2, a0 + 6144u); ldAp(A3, a0 + 9216u);
+    }
+    unsigned xoff[XPASS];
+#pragma unroll
+    for (int q = 0; q < XPASS; ++q) {
+        const int gr = n0 - p.halo_lo + q * RPS + srow;
+        xoff[q] = ((q * RPS < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
+    }
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __builtin_amdgcn_s_setprio(3);
+        ev_lds_barrier();                               // the previous chunk's MFMAs are done with the tile
+        {
+            const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+#pragma unroll
+            for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                if (q0 * RPS >= xrows) continue;
+                f32x4 xg[XG];
+#pragma unroll
+                for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff[q0 + q], soff);      // (passes beyond the tile re-read row 0)
+#pragma unroll
+                for (int q = 0; q < XG; ++q) {
+                    const int r = (q0 + q) * RPS + srow;
+                    f32x4 v = xg[q];
+                    if (p.pro_lrelu) {
+                        v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                        v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                    }
+                    uint2 q0v, q1v, q2v;
+                    evx_split4(v, q0v, q1v, q2v);
+                    if (r < xrows) {
+                        char* dst = Xb + r * EVX_RSB + sc4 * 2;
+                        *(uint2*)(dst) = q0v; *(uint2*)(dst + EVX_KC * 2) = q1v; *(uint2*)(dst + EVX_KC * 4) = q2v;
+                    }
+                }
+            }
+        }
+        ev_lds_barrier();
+        __builtin_amdgcn_s_setprio(0);
+        const char* brow = bbase + tv_first.y * EVX_RSB;
+        ldB(B0, brow, 0);
+        for (int ti = 0; ti < nact; ++ti) {
+            const bool last_tap = (ti + 1 == nact);
+            const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
+            const char* nbrow = bbase + ntv.y * EVX_RSB;
+            const bool have_next = !(last_tap && ch + 1 == nchunks);
+            const unsigned nap = have_next ? a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4) : a_off(tv_first.x, 0);   // unconditional loads
+            ldB(B1, brow, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            evx_mma<TM, TN, TERMS>(acc, A0, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A0, nap);
+            ldB(B0, brow, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            evx_mma<TM, TN, TERMS>(acc, A1, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A1, nap + 3072u);
+            ldB(B1, brow, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            evx_mma<TM, TN, TERMS>(acc, A2, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A2, nap + 6144u);
+            ldB(B0, nbrow, 0);                          // (after a chunk's last tap: a harmless read of the tile being retired)
+            __builtin_amdgcn_sched_barrier(0);
+            evx_mma<TM, TN, TERMS>(acc, A3, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A3, nap + 9216u);
+            brow = nbrow;
+        }
+    }
+    __builtin_amdgcn_s_setprio(3);
+    conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
 // ---------------------------------------------------------------------------
