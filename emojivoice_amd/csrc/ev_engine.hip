@@ -216,7 +216,7 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                         }
         if (dev_upload(h, Wf, &L.W)) return 1;
     }
-    if (L.Kpad % EVX_KC == 0) {   // conv_split_kernel: w = w0 + w1 + w2 exactly, each piece the upper half of an fp32 word (bf16);
+    if (L.Kpad % 16 == 0) {   // conv_split_kernel / resblock_pair_split_kernel: w = w0 + w1 + w2 exactly, each piece the upper half of an fp32 word (bf16);
         // order [tap][Mpad/32][Kpad/16][piece][lane][8], lane = (row & 31) + 32 * half, element e <-> k = 16 kg + 8 half + e
         const int MT32 = L.Mpad / 32, KG16 = L.Kpad / 16;
         std::vector<unsigned short> Wx(Wh.size() * 3);
@@ -472,7 +472,9 @@ void launch_split(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     else if (lean_acc(p)) { ensure_dyn_smem<conv_split_kernel<BM, BN, WM, WN, 3, TERMS>>(smem, lo.device); hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, 3, TERMS>), grid, dim3(256), smem, st, p); }
     else { ensure_dyn_smem<conv_split_kernel<BM, BN, WM, WN, 1, TERMS>>(smem, lo.device); hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, 1, TERMS>), grid, dim3(256), smem, st, p); }
 }
-inline bool split_ok(const ConvLayer& L, const ConvParams& p) {
+inline bool split_ok(const ConvLayer& L, const ConvParams& p0) {
+    ConvParams p = p0;
+    p.dbg &= ~4;                                        // (the no-epilogue ablation of tools/conv_bench.py exists in this build too)
     return L.Wx && lean_ok(p) && p.isplit_log2 >= 31 && L.Cin % EVX_KC == 0 && L.Cin == L.Kpad && L.Mpad % 128 == 0 && ((size_t)p.bias & 15) == 0;
 }
 
@@ -790,7 +792,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     p.ntaps = L2.ntaps; p.taplist = L2.taplist[0]; p.tl_stride = 0; p.nact_tab = nullptr;
     p.pro_lrelu = 1; p.pro_slope = 0.1f;
     p.scale = 1.f; p.R = X; p.ldr = C; p.accum = e.accum; p.div3 = e.div3; p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope;
-    pp.W1 = L1.W; pp.b1 = L1.bias; pp.taplist1 = L1.taplist[0]; pp.ntaps1 = L1.ntaps;
+    pp.W1 = L1.W; pp.W1x = L1.Wx; p.Wx = L2.Wx; pp.b1 = L1.bias; pp.taplist1 = L1.taplist[0]; pp.ntaps1 = L1.ntaps;
     pp.h1 = L1.halo_lo; pp.h2 = L2.halo_lo; pp.mid_slope = 0.1f;
     if ((double)g.nrows * C * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
     if (L1.sparse_taps || L2.sparse_taps || L1.Kpad != C || L2.Kpad != C || L1.Kpad != L2.Kpad || L1.Mpad != L2.Mpad || L1.halo_lo != L1.halo_hi ||
@@ -806,7 +808,21 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     }
     static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
     const int lean = no_lean ? 0 : ((e.accum || e.div3 || e.act2_lrelu) ? 3 : 1);
-    if (C == 32) {
+    static const int split_terms = getenv("EV_SPLIT") ? atoi(getenv("EV_SPLIT")) : 6;
+    const bool split = split_terms > 0 && lean != 0 && L1.Wx && L2.Wx && !(e.force_cfg == 0);
+    if (split) {   // the bf16-split build: LDS rows hold all C channels as three bf16 planes
+        const int NT = C == 32 ? 256 : C == 64 ? 128 : 64, RSB = 6 * C + 16;
+        if (C != 32 && C != 64 && C != 128) return fail(h, "launch_pair: C must be 32, 64 or 128");
+        pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
+        const size_t xs = (size_t)(NT + ((2 * pp.h1 + 7) & ~7)) * RSB, ys = (size_t)(NT + 16) * RSB, es = (size_t)4 * 32 * 36 * sizeof(float);
+        const size_t smem = std::max(xs, std::max(ys, es));
+        const dim3 grid(p.ntiles);
+#define EV_PAIR_SPLIT(WM, WN) do { \
+            if (lean == 1) { ensure_dyn_smem<resblock_pair_split_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_split_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, pp); } \
+            else { ensure_dyn_smem<resblock_pair_split_kernel<WM, WN, 3>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_split_kernel<WM, WN, 3>), grid, dim3(256), smem, h->stream, pp); } } while (0)
+        if (C == 32) EV_PAIR_SPLIT(1, 4); else if (C == 64) EV_PAIR_SPLIT(2, 2); else EV_PAIR_SPLIT(4, 1);
+#undef EV_PAIR_SPLIT
+    } else if (C == 32) {
         constexpr int NT = 256;
         pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
         // exact X-tile rows (NT + 2*h1) instead of NT + EV_HALO: 39 KB instead of 46 KB for k = 3 / 7 -> 4 workgroups per CU
@@ -840,7 +856,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         const double valid_rows = (double)(g.nrows / g.S) * g.T;
         h->prof_flops += 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows;
         h->prof_launches += 1;
-        h->prof_recs.push_back({1, C, C, L1.ntaps, g.nrows, 100 + L2.ntaps, lean, 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows});
+        h->prof_recs.push_back({1, C, C, L1.ntaps, g.nrows, (split ? 140 : 100) + L2.ntaps, lean, 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows});
     }
     return 0;
 }

@@ -914,8 +914,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvParams p) 
     }
     for (int ch = 0; ch < nchunks; ++ch) {
         __builtin_amdgcn_s_setprio(3);
-        ev_lds_barrier();                               // the previous chunk's MFMAs are done with the tile
-        {
+        if (!(p.dbg & 8)) ev_lds_barrier();             // the previous chunk's MFMAs are done with the tile
+        if (!(p.dbg & 64) || ch == 0) {                 // (dbg 64: stage the first chunk only — timing ablation)
             const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
 #pragma unroll
             for (int q0 = 0; q0 < XPASS; q0 += XG) {
@@ -932,7 +932,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvParams p) 
                         v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
                     }
                     uint2 q0v, q1v, q2v;
-                    evx_split4(v, q0v, q1v, q2v);
+                    if (p.dbg & 32) { q0v.x = __float_as_uint(v[0]); q0v.y = __float_as_uint(v[1]); q1v = q0v; q2v = q0v; }   // tools/conv_bench.py ablation: no split arithmetic (timing only)
+                    else evx_split4(v, q0v, q1v, q2v);
                     if (r < xrows) {
                         char* dst = Xb + r * EVX_RSB + sc4 * 2;
                         *(uint2*)(dst) = q0v; *(uint2*)(dst + EVX_KC * 2) = q1v; *(uint2*)(dst + EVX_KC * 4) = q2v;
@@ -940,7 +941,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvParams p) 
                 }
             }
         }
-        ev_lds_barrier();
+        if (!(p.dbg & 8)) ev_lds_barrier();
         __builtin_amdgcn_s_setprio(0);
         const char* brow = bbase + tv_first.y * EVX_RSB;
         ldB(B0, brow, 0);
@@ -974,6 +975,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvParams p) 
         }
     }
     __builtin_amdgcn_s_setprio(3);
+    if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
     conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
 }
 
@@ -1648,6 +1650,7 @@ __global__ __launch_bounds__(512, 4) void conv_sk32_kernel(const ConvParams pk) 
 struct PairParams {
     ConvParams c2;                 // c2 + epilogue view: X = x (input), W/bias/taplist = c2's, R = x, Y = output, flags
     const float* W1; const float* b1; const int2* taplist1; int ntaps1;
+    const void* W1x;               // resblock_pair_split_kernel: c1's weights as three bf16 pieces (c2's: c2.Wx)
     int h1, h2;                    // halos of c1 (dilated) and c2
     float mid_slope;               // leaky-relu slope between the convs
     int out_rows;                  // NT - 2*h2
@@ -1825,6 +1828,185 @@ __global__ __launch_bounds__(256, WAVES_M == 2 ? 4 : 3) void resblock_pair_kerne
     // ---------------- epilogue: + b2 + x (residual re-read, L2-hot), optional running resblock mean, window [n0, n0 + out_rows)
     if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
     else conv_epilogue<TM, TN, false>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
+}
+
+// ---------------------------------------------------------------------------
+// resblock_pair_split_kernel: resblock_pair_kernel on the bf16 matrix pipe (see conv_split_kernel: six exact bf16 products per
+// element pair, fp32 accumulation).  Same tile geometry (compute rows NT, waves = channel tiles x row tiles, wave tile 32 channels
+// x 64 rows).  LDS rows hold ALL C channels as three bf16 planes (row stride 6 C + 16 bytes: 208 / 400 / 784, odd multiples of 16),
+// so x is staged — and split — once, and the intermediate y1 = lrelu(c1 + b1) is split as it leaves the accumulators (register
+// 4 g + e of a lane = four consecutive channels of one row: one 8-byte store per piece).  K loop: the (tap, 16-deep slab) sequence
+// in groups of two slabs, weight fragments two groups ahead in four named sets, activation fragments double-buffered by slab.
+// ---------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int LEAN, int TERMS = 6>
+__global__ __launch_bounds__(256, 2) void resblock_pair_split_kernel(const PairParams pp) {
+    constexpr int TM = 1, TN = 2;
+    constexpr int C = 32 * WAVES_M;
+    constexpr int NT = WAVES_N * TN * 32;
+    constexpr int RSB = 6 * C + 16;                     // LDS row stride in bytes
+    constexpr int NS = C / 16, H = NS / 2;              // slabs per tap; two-slab groups per tap
+    constexpr int TPR = C / 4, RPS = 256 / TPR;         // staging: threads per row, rows per pass
+    constexpr int XPASS = (NT + EV_HALO) / RPS;
+    constexpr int XG = XPASS > 8 ? XPASS / 2 : XPASS;
+    static_assert(WAVES_M * WAVES_N == 4 && XPASS % XG == 0, "4 waves per workgroup");
+    const ConvParams& p = pp.c2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;                             // phase 1: [NT + 2 h1][RSB];  phase 2 (aliased): y1 [NT + 2 h2][RSB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+    const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
+
+    const int nt = ev_xcd_remap(blockIdx.x, p.ntiles);
+    const int n0 = nt * pp.out_rows;
+    const int g0 = n0 - pp.h2;
+    {   // tiles whose output window holds no storable row do nothing
+        const int s0 = n0 % p.S, t_first = s0 - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - s0 + p.P;
+        if (dist >= pp.out_rows || n0 + dist >= p.nrows) return;
+    }
+    const int KG16 = p.Kpad >> 4;
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned wbase = (unsigned)(wm * KG16) * 3072u;
+    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(p.X);
+    f32x16 acc[TM][TN];
+    f32x4 A0[3][TM], A1[3][TM], A2[3][TM], A3[3][TM], B0[3][TN], B1[3][TN];
+
+    auto ldAp = [&](const __amdgpu_buffer_rsrc_t& rW, f32x4 (&dst)[3][TM], unsigned aoff) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) dst[pc][0] = ev_bload4(rW, wlane, aoff + (unsigned)(pc * 1024));
+    };
+    auto ldB = [&](f32x4 (&dst)[3][TN], const char* brow, int slab) {
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dst[pc][j] = *(const f32x4*)(brow + j * 32 * RSB + pc * (2 * C) + slab * 32);
+    };
+    // group g of a phase = slabs 2 (g % H), 2 (g % H) + 1 of tap g / H; byte offset of its first weight fragment (tap-list entries
+    // carry the fp32 plane offset: a split plane is 1.5 x that)
+    auto g_off = [&](int2 tlv, int g, int ngroups) -> unsigned {
+        const int gg = g < ngroups ? g : 0;             // (beyond the phase: a harmless re-read)
+        const unsigned tb = (unsigned)__builtin_amdgcn_readlane(tlv.x, gg / H);
+        return tb + (tb >> 1) + wbase + (unsigned)(2 * (gg % H)) * 3072u;
+    };
+    auto g_row = [&](int2 tlv, int g, int ngroups) -> int {
+        const int gg = g < ngroups ? g : 0;
+        return __builtin_amdgcn_readlane(tlv.y, gg / H);
+    };
+    auto acc_init = [&](const float* binit) {
+        f32x4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *(const f32x4*)(binit + wm * 32 + 8 * g + 4 * lh);
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][b][r] = bq[r >> 2][r & 3];
+    };
+    auto ring_fill = [&](const __amdgpu_buffer_rsrc_t& rW, int2 tlv, int ngroups) {
+        const unsigned o0 = g_off(tlv, 0, ngroups), o1 = g_off(tlv, 1, ngroups);
+        ldAp(rW, A0, o0); ldAp(rW, A1, o0 + 3072u); ldAp(rW, A2, o1); ldAp(rW, A3, o1 + 3072u);
+    };
+    // the K loop of one conv: `bbase` = this lane's LDS row 0 (halo already added), fragments of groups 0 and 1 already requested
+    auto kloop = [&](const __amdgpu_buffer_rsrc_t& rW, int2 tlv, int ngroups, const char* bbase) {
+        auto group = [&](f32x4 (&Aa)[3][TM], f32x4 (&Ab)[3][TM], int g) {
+            const char* brow = bbase + g_row(tlv, g, ngroups) * RSB;
+            const char* nbrow = bbase + g_row(tlv, g + 1, ngroups) * RSB;
+            const int s0 = 2 * (g % H), ns0 = 2 * ((g + 1) % H);
+            const unsigned nap = g_off(tlv, g + 2, ngroups);
+            ldB(B1, brow, s0 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            evx_mma<TM, TN, TERMS>(acc, Aa, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(rW, Aa, nap);
+            ldB(B0, nbrow, ns0);
+            __builtin_amdgcn_sched_barrier(0);
+            evx_mma<TM, TN, TERMS>(acc, Ab, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(rW, Ab, nap + 3072u);
+        };
+        ldB(B0, bbase + g_row(tlv, 0, ngroups) * RSB, 0);
+        int g = 0;
+        for (; g + 1 < ngroups; g += 2) { group(A0, A1, g); group(A2, A3, g + 1); }
+        if (g < ngroups) group(A0, A1, g);
+    };
+
+    // ---------------- phase 1: c1 over lrelu(x); X tile rows [g0 - h1, g0 + NT + h1), all channels, split into three planes
+    const __amdgpu_buffer_rsrc_t rW1 = ev_rsrc(pp.W1x), rW2 = ev_rsrc(p.Wx);
+    const int ng1 = pp.ntaps1 * H, ng2 = p.ntaps * H;
+    const int2 tlv1 = (lane < pp.ntaps1) ? pp.taplist1[lane] : make_int2(0, 0);
+    const int2 tlv2 = (lane < p.ntaps) ? p.taplist[lane] : make_int2(0, 0);
+    ring_fill(rW1, tlv1, ng1);
+    acc_init(pp.b1);
+    {
+        const int xrows = NT + 2 * pp.h1;
+#pragma unroll
+        for (int q0 = 0; q0 < XPASS; q0 += XG) {
+            if (q0 * RPS >= xrows) continue;
+            f32x4 xg[XG];
+#pragma unroll
+            for (int q = 0; q < XG; ++q) {
+                const int r = (q0 + q) * RPS + srow;
+                const int gr = g0 - pp.h1 + r;
+                xg[q] = ev_bload4(rX, ((r < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u, 0);   // (row 0 is a zero pad row)
+            }
+#pragma unroll
+            for (int q = 0; q < XG; ++q) {
+                const int r = (q0 + q) * RPS + srow;
+                f32x4 v = xg[q];
+                v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                uint2 q0v, q1v, q2v;
+                evx_split4(v, q0v, q1v, q2v);
+                if (r < xrows) {
+                    char* dst = Xb + r * RSB + sc4 * 2;
+                    *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v; *(uint2*)(dst + 4 * C) = q2v;
+                }
+            }
+        }
+    }
+    ev_lds_barrier();
+    kloop(rW1, tlv1, ng1, Xb + (wn * (TN * 32) + li + pp.h1) * RSB + 16 * lh);
+    ring_fill(rW2, tlv2, ng2);                           // c2's first fragments fly under the hand-over below
+
+    // ---------------- y1 = lrelu(c1 + b1), zero outside the utterance, split, into LDS rows r + h2
+    ev_lds_barrier();                                    // every wave is done reading the X tile
+    {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * (TN * 32) + j * 32 + li;
+            const int n = g0 + r;
+            const int t = (n >= 0 && n < p.nrows) ? (n % p.S) - p.P : -1;
+            const float inside = (t >= 0 && t < p.T) ? 1.f : 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ev_lrelu(acc[0][j][4 * g + e], pp.mid_slope) * inside;
+                uint2 q0v, q1v, q2v;
+                evx_split4(v, q0v, q1v, q2v);
+                char* dst = Xb + (r + pp.h2) * RSB + (wm * 32 + 8 * g + 4 * lh) * 2;
+                *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v; *(uint2*)(dst + 4 * C) = q2v;
+            }
+        }
+        // the 2 h2 border rows only feed outputs outside the stored window, but must be finite: zero all three planes
+        for (int i = tid; i < 2 * pp.h2 * (6 * C / 16); i += 256) {
+            const int br = i / (6 * C / 16), c16 = i % (6 * C / 16);
+            const int row = br < pp.h2 ? br : NT + br;
+            uint4 z = {0u, 0u, 0u, 0u};
+            *(uint4*)(Xb + row * RSB + c16 * 16) = z;
+        }
+    }
+    acc_init(LEAN ? p.bias : pp.b1);
+    ev_lds_barrier();
+
+    // ---------------- phase 2: c2 over the LDS-resident y1 (tap offset t reads rows r + h2 + t)
+    kloop(rW2, tlv2, ng2, Xb + (wn * (TN * 32) + li + pp.h2) * RSB + 16 * lh);
+
+    conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
 }
 
 // ---------------------------------------------------------------------------
