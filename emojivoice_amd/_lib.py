@@ -21,7 +21,7 @@ CSRC = os.path.join(_HERE, "csrc")
 EXPORTS = [
     "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder", "ev_load_text_encoder", "ev_text_encoder",
     "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
-    "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read",
+    "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read", "ev_profile_read_split", "ev_dbg_last_cfg",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention", "ev_op_ln_mlp", "ev_set_mrf_streams_max",
     "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out",
 ]
@@ -97,6 +97,8 @@ def load_library() -> C.CDLL:
     lib.ev_denoise.argtypes = [vp, vp, i32, i32, vp, f32, vp, vp]
     lib.ev_profile_enable.argtypes = [vp, i32]
     lib.ev_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+    lib.ev_profile_read_split.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.ev_dbg_last_cfg.argtypes = [vp]
     lib.ev_op_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
     lib.ev_op_groupnorm_mish.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ev_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
@@ -317,6 +319,15 @@ class Engine:
     # ---- profiling hooks (bench.py) -------------------------------------------
     def profile_enable(self, on: bool):
         self._check(self.lib.ev_profile_enable(self.h, int(on)), "ev_profile_enable")
+
+    def last_cfg(self) -> int:
+        return int(self.lib.ev_dbg_last_cfg(self.h))
+
+    def profile_read_split(self):
+        """(ms, flops, launches) of the bf16-split builds among the launches recorded since the last reset."""
+        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.ev_profile_read_split(self.h, C.byref(ms), C.byref(fl), C.byref(n)), "ev_profile_read_split")
+        return ms.value, fl.value, n.value
 
     def profile_read(self, reset: bool = True):
         ms, fl, n = C.c_double(), C.c_double(), C.c_int64()

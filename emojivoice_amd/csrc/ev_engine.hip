@@ -148,6 +148,7 @@ struct ev_handle {
     int ncu = 0;                    // compute units of the device
     unsigned* sk_ctrl = nullptr;    // [0] epoch [1] arrivals [2] timed-out waits | flags from word 16 on
     float* sk_part = nullptr;
+    int last_cfg = -1;              // build the last launch_conv / launch_pair took (ev_dbg_last_cfg: tests assert that a shape ran on the build they mean)
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
     bool sk_spread = false;         // EV_SK_SPREAD=1: launches of fewer row tiles than CUs (small batches) spread their units over up to 2 x CUs workgroups
     int sk_wgs = 2;                 // EV_SK_WGS=<1..3>: persistent workgroups per CU of a balanced ln_mlp launch (A/B runs)
@@ -545,6 +546,30 @@ int launch_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc, unsign
     else { ensure_dyn_smem<conv_gemm_bal_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_gemm_bal_kernel<BM, BN, WM, WN, 1>), dim3(G), dim3(256), smem, h->stream, p); }
     return 0;
 }
+// ... and of the bf16-split build (conv_split_bal_kernel): a unit = (tile, 64-channel chunk)
+template <int BM, int BN, int WM, int WN>
+int launch_split_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
+    if (ensure_sk(h)) return 1;
+    const int nchunks = p.Kpad / EVX_KC;
+    const long U = (long)p.mtiles * p.ntiles * nchunks;
+    const int G = wpc * h->ncu;
+    p.sk.ctrl = h->sk_ctrl; p.sk.flags = h->sk_ctrl + 16; p.sk.part = h->sk_part; p.sk.part_floats = EV_SK_PART_FLOATS;
+    p.sk.q = (int)(U / G); p.sk.r = (int)(U % G); p.sk.spin_limit = h->sk_spin;
+    const size_t xs = (size_t)(BN + ((lo.halo + 7) & ~7)) * EVX_RSB;
+    constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4) * sizeof(float);
+    size_t smem = xs > es ? xs : es;
+    p.sk.lds_word = (int)smem;
+    smem += 16;
+    static_assert((size_t)BM * BN <= EV_SK_PART_FLOATS, "hand-off slot");
+    if (lean_acc(p)) { ensure_dyn_smem<conv_split_bal_kernel<BM, BN, WM, WN, 3>>(smem, lo.device); hipLaunchKernelGGL((conv_split_bal_kernel<BM, BN, WM, WN, 3>), dim3(G), dim3(256), smem, h->stream, p); }
+    else { ensure_dyn_smem<conv_split_bal_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_split_bal_kernel<BM, BN, WM, WN, 1>), dim3(G), dim3(256), smem, h->stream, p); }
+    return 0;
+}
+inline bool split_bal_ok(const ev_handle* h, const ConvLayer& L, const ConvParams& p, long nwg, int wpc) {
+    static const bool off = getenv("EV_NO_CONV_BALANCE") != nullptr;
+    return !off && h->sk_balance && h->ncu > 0 && split_ok(L, p) && p.act != ACT_SNAKE && !p.dbg && !p.stamps && !p.gn_part &&
+           nwg * 2 >= h->ncu && wpc * h->ncu <= EV_SK_MAXWG && (long)nwg * (p.Kpad / EVX_KC) >= (long)wpc * h->ncu;
+}
 // A conv launch takes the balanced build when it is dense (every tap in every M tile: equal units), has a lean non-transcendental
 // epilogue, fills at least one tile per CU and at most a few rounds (deep grids balance by themselves), and the tile's accumulators fit
 // a hand-off slot.
@@ -653,8 +678,12 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     }
     {   // deep grids of dense-channel layers: the bf16-split build (EV_SPLIT=0: fp32 MFMA everywhere; 3 / 9: products per element pair, A/B)
         static const int split_terms = getenv("EV_SPLIT") ? atoi(getenv("EV_SPLIT")) : 6;
-        if (split_terms > 0 && (cfg == 0 || cfg == 1 || cfg == 5) && split_ok(L, p) && (long)(L.Mpad / 128) * ((g.nrows + 127) / 128) >= 256L * 2 * 3)
+        // (polyphase transposed convs keep the fp32 build: their 64-channel M tiles carry different tap subsets, a 128-channel tile the union)
+        const long nwg128 = (long)(L.Mpad / 128) * ((g.nrows + 127) / 128);
+        if (split_terms > 0 && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && !L.sparse_taps && nwg128 >= 2L * 2 * h->ncu && h->ncu > 0)
             cfg = split_terms == 3 ? 43 : split_terms == 9 ? 49 : 40;
+        // launches of a few rounds (the U-Net convs of a large-batch decode): the balanced persistent grid of the split build
+        else if (split_terms == 6 && (cfg == 1 || cfg == 5 || cfg == 6 || cfg == 0) && L.Cout == L.Mpad && split_bal_ok(h, L, p, nwg128, 2)) cfg = 60;
     }
     {   // debugging / test override: EV_FORCE_CFG=<0..3> forces one tile configuration for every conv launch
         static const char* env = getenv("EV_FORCE_CFG");
@@ -684,7 +713,11 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         static const char* senv = getenv("EV_STAGGER");
         if (senv && *senv) p.stagger_slots = atoi(senv) ? p.stagger_slots : 0;
     }
-    if ((cfg == 40 || cfg == 43 || cfg == 49) && !split_ok(L, p)) cfg = 0;
+    if ((cfg == 40 || cfg == 43 || cfg == 49 || cfg == 60) && !split_ok(L, p)) cfg = 0;
+    if (cfg == 60) {   // 128 x 128 on the bf16 pipe, balanced persistent grid
+        p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        if (launch_split_bal<128, 128, 2, 2>(h, p, lo, 2)) return 1;
+    } else
     if (cfg == 40 || cfg == 43 || cfg == 49) {   // 128 x 128 on the bf16 pipe
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         if (cfg == 40) launch_split<128, 128, 2, 2, 6>(p, h->stream, lo);
@@ -770,6 +803,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         launch_cfg<32, 256, 1, 4>(p, h->stream, lo);
     }
     HIPCHK(h, hipGetLastError());
+    h->last_cfg = cfg;
     if (h->prof) {
         HIPCHK(h, hipEventRecord(e1, h->stream));
         const double valid_rows = (double)(g.nrows / g.S) * g.T;
@@ -851,6 +885,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         return fail(h, "launch_pair: C must be 32, 64 or 128");
     }
     HIPCHK(h, hipGetLastError());
+    h->last_cfg = (split ? 140 : 100) + L2.ntaps;
     if (h->prof) {
         HIPCHK(h, hipEventRecord(e1, h->stream));
         const double valid_rows = (double)(g.nrows / g.S) * g.T;
@@ -2260,6 +2295,30 @@ int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* 
     if (conv_flops) *conv_flops = h->prof_flops;
     if (conv_launches) *conv_launches = h->prof_launches;
     if (reset) { h->ev_used = 0; h->prof_flops = 0; h->prof_launches = 0; h->prof_recs.clear(); }
+    return 0;
+}
+
+int ev_dbg_last_cfg(ev_handle* h) { return h ? h->last_cfg : -1; }
+
+// The launches of the bf16-split builds (conv_split_kernel, conv_split_bal_kernel, resblock_pair_split_kernel) among those recorded
+// since the last reset: call before ev_profile_read(..., reset = 1).
+int ev_profile_read_split(ev_handle* h, double* ms_out, double* flops_out, int64_t* launches_out) {
+    if (!h) return 1;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double ms = 0, fl = 0;
+    int64_t n = 0;
+    if (h->prof_recs.size() * 2 == h->ev_used)
+        for (size_t i = 0; i < h->prof_recs.size(); ++i) {
+            const auto& r = h->prof_recs[i];
+            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140);
+            if (!split) continue;
+            float t = 0;
+            HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
+            ms += t; fl += r.flops; n += 1;
+        }
+    if (ms_out) *ms_out = ms;
+    if (flops_out) *flops_out = fl;
+    if (launches_out) *launches_out = n;
     return 0;
 }
 

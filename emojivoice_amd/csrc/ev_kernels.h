@@ -1220,6 +1220,226 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bal_kernel(const ConvParams 
     sk_arrive(p.sk, tag, tid);
 }
 
+// ---------------------------------------------------------------------------
+// conv_split_bal_kernel: the balanced persistent grid of conv_gemm_bal_kernel with the K loop of conv_split_kernel (bf16 pipe, six
+// exact products per element pair).  A unit = (tile, 64-channel chunk); hand-off, tags, bounded waits and the recompute fallback
+// are those of SkCtl.  Layers whose M tiles carry different tap counts (a 3-tap conv stacked over a 1x1 conv) take it too, with
+// equal unit weights: the 128-channel tiles fall on either side of the stacking boundary.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN, int TERMS = 6>
+__global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams p) {
+    constexpr int TM = BM / WAVES_M / 32;
+    constexpr int TN = BN / WAVES_N / 32;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1 && LEAN != 0, "balanced build: 4 waves, lean epilogue");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nchunks = p.Kpad / EVX_KC;
+    const int g = blockIdx.x;
+    const unsigned tag = sk_tag(p.sk);
+    int u = sk_start(p.sk, g);
+    const int ue = sk_start(p.sk, g + 1);
+    const __amdgpu_buffer_rsrc_t rPart = ev_rsrc(p.sk.part), rW = ev_rsrc(p.Wx), rX = ev_rsrc(p.X);
+    const unsigned pslot = (unsigned)p.sk.part_floats * 8u;
+    constexpr int PN = TM * TN * 4;
+    const unsigned pelem = (unsigned)(wave * PN) * 1024u + (unsigned)lane * 16u;
+    int* skw = (int*)((char*)smem + p.sk.lds_word);
+    bool pend_pub = false;
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int KG16 = p.Kpad >> 4;
+    constexpr int TPR = EVX_KC / 4, RPS = 256 / TPR;
+    const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
+    constexpr int XPASS = (BN + EV_HALO) / RPS;
+    constexpr int XG = 4;
+    static_assert(XPASS % XG == 0, "staging batches");
+    const int xrows = BN + p.halo_lo + p.halo_hi;
+
+    while (u < ue) {
+        const int t = u / nchunks, c0 = u - t * nchunks;
+        const int c1 = (ue - u < nchunks - c0) ? c0 + (ue - u) : nchunks;
+        u += c1 - c0;
+        const int mt = t % p.mtiles, nt = t / p.mtiles;
+        const int m0 = mt * BM, n0 = nt * BN;
+        {   // tiles that contain no storable row (pure padding) do nothing — owner and contributors agree, the test only reads t
+            int t_first = (n0 % p.S) - p.P;
+            int dist;
+            if (t_first >= 0 && t_first < p.T) dist = 0;
+            else if (t_first < 0) dist = -t_first;
+            else dist = p.S - (n0 % p.S) + p.P;
+            if (dist >= BN || n0 + dist >= p.nrows) continue;
+        }
+        if (pend_pub) { sk_publish(p.sk, g, tag, tid); pend_pub = false; }
+        const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
+        const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
+        const int mt32 = (m0 + wm * (TM * 32)) >> 5;
+        const unsigned wbase = (unsigned)(mt32 * KG16) * 3072u;
+        auto a_off = [&](int tap_bytes, int kg16) -> unsigned { return (unsigned)tap_bytes + ((unsigned)tap_bytes >> 1) + wbase + (unsigned)kg16 * 3072u; };
+        f32x4 A0[3][TM], A1[3][TM], A2[3][TM], A3[3][TM], B0[3][TN], B1[3][TN];
+        auto ldAp = [&](f32x4 (&dst)[3][TM], unsigned aoff) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) dst[pc][i] = ev_bload4(rW, wlane, aoff + (unsigned)(i * KG16 * 3072 + pc * 1024));
+        };
+        auto ldB = [&](f32x4 (&dst)[3][TN], const char* brow, int slab) {
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) dst[pc][j] = *(const f32x4*)(brow + j * 32 * EVX_RSB + pc * (EVX_KC * 2) + slab * 32);
+        };
+        const char* bbase = Xb + (wn * (TN * 32) + li + p.halo_lo) * EVX_RSB + 16 * lh;
+        const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
+        const int2 tv_first = ev_tap_at(tlv, 0);
+        const int gr0 = n0 - p.halo_lo + srow;             // first staging row of this thread (rows outside the tensor / the tile read pad row 0)
+        auto xoff = [&](int q) -> unsigned {
+            const int gr = gr0 + q * RPS;
+            return ((q * RPS < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
+        };
+        int cA = c0, cB = c1;
+        bool spilled = false;
+        int gi = g + 1;
+        const int tile_end = (t + 1) * nchunks;
+        for (;;) {
+            f32x16 acc[TM][TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                f32x4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    bq[q] = z;
+                    const int cc = m0 + wm * (TM * 32) + a * 32 + 8 * q + 4 * lh;   // bias preloaded (lean epilogue), by the owner's first pass only
+                    if (p.bias && cA == 0 && cc < p.Cout) bq[q] = *(const f32x4*)(p.bias + cc);
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = bq[r >> 2][r & 3];
+            }
+            if (nact > 0) {
+                const unsigned a0 = a_off(tv_first.x, cA * 4);
+                ldAp(A0, a0); ldAp(A1, a0 + 3072u); ldAp(A2, a0 + 6144u); ldAp(A3, a0 + 9216u);
+            }
+            for (int ch = cA; ch < cB; ++ch) {
+                __builtin_amdgcn_s_setprio(3);
+                ev_lds_barrier();                          // the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
+                {
+                    const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+#pragma unroll
+                    for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                        if (q0 * RPS >= xrows) continue;
+                        f32x4 xg[XG];
+#pragma unroll
+                        for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff(q0 + q), soff);
+#pragma unroll
+                        for (int q = 0; q < XG; ++q) {
+                            const int r = (q0 + q) * RPS + srow;
+                            f32x4 v = xg[q];
+                            if (p.pro_lrelu) {
+                                v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                                v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                            }
+                            uint2 q0v, q1v, q2v;
+                            evx_split4(v, q0v, q1v, q2v);
+                            if (r < xrows) {
+                                char* dst = Xb + r * EVX_RSB + sc4 * 2;
+                                *(uint2*)(dst) = q0v; *(uint2*)(dst + EVX_KC * 2) = q1v; *(uint2*)(dst + EVX_KC * 4) = q2v;
+                            }
+                        }
+                    }
+                }
+                ev_lds_barrier();
+                __builtin_amdgcn_s_setprio(0);
+                const char* brow = bbase + tv_first.y * EVX_RSB;
+                ldB(B0, brow, 0);
+                for (int ti = 0; ti < nact; ++ti) {
+                    const bool last_tap = (ti + 1 == nact);
+                    const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
+                    const char* nbrow = bbase + ntv.y * EVX_RSB;
+                    const bool have_next = !(last_tap && ch + 1 == cB);
+                    const unsigned nap = have_next ? a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4) : a_off(tv_first.x, cA * 4);
+                    ldB(B1, brow, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    evx_mma<TM, TN, TERMS>(acc, A0, B0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A0, nap);
+                    ldB(B0, brow, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    evx_mma<TM, TN, TERMS>(acc, A1, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A1, nap + 3072u);
+                    ldB(B1, brow, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    evx_mma<TM, TN, TERMS>(acc, A2, B0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A2, nap + 6144u);
+                    ldB(B0, nbrow, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    evx_mma<TM, TN, TERMS>(acc, A3, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A3, nap + 9216u);
+                    brow = nbrow;
+                }
+            }
+            auto acc_io = [&](unsigned base, int mode) {    // mode 0: store (write-through), 1: add from memory
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned off = base + pelem + (unsigned)((a * TN + b) * 4 + q) * 1024u;
+                            if (mode == 0) {
+                                const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                                ev_bstore4_sc1(rPart, off, v);
+                            } else {
+                                const f32x4 v = ev_bload4_sc1(rPart, off);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[a][b][4 * q + e] += v[e];
+                            }
+                        }
+            };
+            if (spilled) { acc_io((unsigned)g * pslot + pslot / 2, 1); spilled = false; }
+            if (c0 != 0) {                                 // not the owner: hand the partial tile over (flag raised at the next segment)
+                acc_io((unsigned)g * pslot, 0);
+                pend_pub = true;
+                break;
+            }
+            bool again = false;
+            while (c1 < nchunks) {                         // owner: add the contributors' partial tiles in ascending workgroup order
+                int n = 0;
+                while (n < 64 && gi + n < (int)gridDim.x && sk_start(p.sk, gi + n) < tile_end) ++n;
+                if (n == 0) break;
+                const int ready = sk_wait_many(p.sk, gi, n, tag, tid, skw);
+                for (int k = 0; k < ready; ++k) acc_io((unsigned)(gi + k) * pslot, 1);
+                gi += ready;
+                if (ready < n) {                           // gi is not there in time: spill the running sum, compute its share here
+                    const int sgi = sk_start(p.sk, gi);
+                    int egi = sk_start(p.sk, gi + 1);
+                    egi = egi < tile_end ? egi : tile_end;
+                    acc_io((unsigned)g * pslot + pslot / 2, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    cA = sgi - t * nchunks; cB = egi - t * nchunks;
+                    spilled = true; again = true;
+                    ++gi;
+                    break;
+                }
+            }
+            if (again) continue;
+            __builtin_amdgcn_s_setprio(3);
+            conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+            __builtin_amdgcn_s_setprio(0);
+            break;
+        }
+    }
+    if (pend_pub) sk_publish(p.sk, g, tag, tid);
+    sk_arrive(p.sk, tag, tid);
+}
+
 // (A loader-wave build of this kernel — two extra waves per workgroup that only stage X tiles, so that the MFMA waves
 // never wait for HBM behind their in-order vmcnt — was built and measured 5-30 % SLOWER on every shape: a wave that
 // streams MFMAs back to back starves every dependent instruction chain of the other waves on its SIMD

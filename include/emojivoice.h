@@ -161,10 +161,17 @@ int ev_stft_magnitude(ev_handle *h, const float *d_audio, int B, int L, float *d
 int ev_denoise(ev_handle *h, const float *d_audio, int B, int L, const float *d_bias_spec, float strength, float *d_out, void *stream);
 
 /* Timing hooks for bench.py: HIP-event time (ms) of the dominant kernel family
- * (fp32-MFMA implicit-GEMM conv) accumulated over the calls since the last reset,
+ * (implicit-GEMM convs, fused pairs, fused LayerNorm + MLP, fused attention) accumulated over the calls since the last reset,
  * measured on the stream the kernels run on. */
 int ev_profile_enable(ev_handle *h, int on);
 int ev_profile_read(ev_handle *h, double *conv_ms, double *conv_flops, int64_t *conv_launches, int reset);
+/* ... and, of those, the launches that ran on the bf16 matrix pipe (conv_split_kernel, conv_split_bal_kernel,
+ * resblock_pair_split_kernel: every fp32 product as six exact bf16 products, fp32 accumulation); call before a resetting
+ * ev_profile_read.  The rest of the family runs on v_mfma_f32_32x32x2_f32. */
+int ev_profile_read_split(ev_handle *h, double *ms, double *flops, int64_t *launches);
+/* Test hook: the build the last conv / fused-pair launch of this handle took (tile configuration id: 40 / 60 = conv_split_kernel /
+ * its balanced grid, 140 + taps = resblock_pair_split_kernel, 100 + taps = resblock_pair_kernel, others: see launch_conv). */
+int ev_dbg_last_cfg(ev_handle *h);
 
 /* Kernel microbenchmark hook (tools/conv_bench.py, not part of the product path): times `iters` launches of one
  * resblock-style conv (prologue leaky-relu, bias, residual) at a given geometry with HIP events on the default stream;

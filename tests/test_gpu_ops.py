@@ -55,6 +55,27 @@ def test_conv1d(eng, B, Cin, T, Cout, K, dil, slope):
     _close(got, ref, what=f"conv {Cin}->{Cout} k{K} d{dil}")
 
 
+@pytest.mark.parametrize("B,Cin,T,Cout,K,dil,slope,cfg", [(5, 128, 30000, 128, 7, 3, 0.1, 40), (3, 256, 23000, 256, 11, 5, 0.1, 40), (2, 128, 40000, 256, 3, 1, -1.0, 40),
+                                                          (16, 256, 600, 256, 3, 1, -1.0, 60), (40, 512, 258, 256, 1, 1, 0.1, 60)])
+def test_conv1d_split_builds(eng, B, Cin, T, Cout, K, dil, slope, cfg):
+    """conv_split_kernel (cfg 40: deep grids) and conv_split_bal_kernel (cfg 60: a few rounds of workgroups): fp32 convs whose products
+    are formed on the bf16 matrix pipe — every fp32 operand is the exact sum of three bf16 pieces, the six products of weight <= 2 are
+    accumulated in fp32 (what is left out is below one fp32 rounding of the product: tools/bf16_split_probe.hip).  Same tolerance
+    against torch's fp32 conv as the fp32-MFMA builds, and bit-reproducible."""
+    g = torch.Generator().manual_seed(B + Cin + T)
+    x = torch.randn(B, Cin, T, generator=g) * 1.5
+    x[:, :, ::7] *= 1e-3                                   # operands of very different magnitude in one dot product
+    w = torch.randn(Cout, Cin, K, generator=g) / (Cin * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    pad = dil * (K - 1) // 2
+    xin = F.leaky_relu(x, slope) if slope >= 0 else x
+    ref = F.conv1d(xin, w, b, padding=pad, dilation=dil)
+    got = eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope)
+    assert eng.last_cfg() == cfg, f"this shape was expected to take build {cfg}, took {eng.last_cfg()}"
+    _close(got, ref, what=f"split conv {Cin}->{Cout} k{K} d{dil}")
+    assert torch.equal(eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope), got)
+
+
 @pytest.mark.parametrize("B,Cin,T,Cout,K,slope", [(64, 256, 196, 256, 3, -1.0), (64, 256, 194, 256, 3, 0.1), (64, 512, 196, 256, 1, -1.0), (48, 256, 283, 256, 3, -1.0)])
 def test_conv1d_balanced_grid(eng, B, Cin, T, Cout, K, slope, monkeypatch):
     """Dense conv launches of about one round of workgroups take conv_gemm_bal_kernel (a balanced persistent grid over (tile,

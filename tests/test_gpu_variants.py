@@ -1,9 +1,11 @@
 """The kernel A/B switches (tile configuration, two-chunk staging, generic instead of lean epilogue, unfused resblock pairs,
 fused LayerNorm + QKV / feed-forward kernels forced on at a small batch or switched off, split-key attention switched off,
 the three ResBlock1 chains of an MRF level on one stream instead of three, the workspace zeroed whole instead of its pad rows,
-the balanced persistent grids and the fused attention + projection kernel at batch 64)
-must not change results: every build accumulates in the same (chunk, tap, k-group) order, so the variants agree with the
-default path to fp32 rounding of the epilogue (bias added before vs after the K loop).  The switches are read once per
+the balanced persistent grids and the fused attention + projection kernel at batch 64, and EV_SPLIT=0: every conv on the fp32 MFMA
+instead of the bf16-split builds)
+must not change results: every fp32-MFMA build accumulates in the same (chunk, tap, k-group) order, so those variants agree with the
+default path to fp32 rounding of the epilogue (bias added before vs after the K loop); the split builds form each product from six
+exact bf16 products and differ from the fp32 MFMA by less than one rounding of the product.  The switches are read once per
 process, hence one child process per variant."""
 import json
 import os
@@ -38,11 +40,11 @@ torch.save({"mel": mel.cpu(), "wav": wav.cpu()}, sys.argv[1])
 
 VARIANTS = [{"EV_KB": "2"}, {"EV_NO_LEAN": "1"}, {"EV_FUSE_PAIRS": "0"}, {"EV_FORCE_CFG": "0"}, {"EV_FORCE_CFG": "5"}, {"EV_FORCE_CFG": "6"},
             {"EV_FORCE_CFG": "4"}, {"EV_FUSE_MLP_MIN": "1"}, {"EV_FUSE_MLP": "0"}, {"EV_NO_ATTN_SK": "1"},
-            {"EV_MRF_STREAMS_MAX": "0"}, {"EV_FULL_REZERO": "1"}]
+            {"EV_MRF_STREAMS_MAX": "0"}, {"EV_FULL_REZERO": "1"}, {"EV_SPLIT": "0"}]
 
 
 # the single-utterance builds: conv_sk32_kernel, per-tile GroupNorm statistics + groupnorm_apply_kernel, split-key attention
-B1_VARIANTS = [{"EV_NO_GN_STATS": "1"}, {"EV_NO_SK32_LEAN": "1"}, {"EV_ATTN_TPW": "1"}, {"EV_ATTN_TPW": "3"}, {"EV_NO_ATTN_SK": "1"}, {"EV_NO_SK": "1"}]
+B1_VARIANTS = [{"EV_SPLIT": "0"}, {"EV_NO_GN_STATS": "1"}, {"EV_NO_SK32_LEAN": "1"}, {"EV_ATTN_TPW": "1"}, {"EV_ATTN_TPW": "3"}, {"EV_NO_ATTN_SK": "1"}, {"EV_NO_SK": "1"}]
 
 
 def _run(tmp_path, name, extra, shape="b3"):
@@ -89,7 +91,7 @@ def test_batch64_balanced_builds(tmp_path):
     nowait = _run(tmp_path, "b64_nowait", {"EV_SK_SPIN": "0"}, "b64")
     assert torch.equal(nowait["mel"], ref["mel"]) and torch.equal(nowait["wav"], ref["wav"])
     # (run-to-run equality of the default build is covered in-process by tests/test_gpu_ops.py; every switch here costs a batch-64 child)
-    for i, extra in enumerate([{"EV_NO_SK_BALANCE": "1"}, {"EV_CONV_BALANCE_W": "1", "EV_BAL5": "64"}, {"EV_FUSE_ATTN": "0", "EV_SK_WGS": "3"}]):
+    for i, extra in enumerate([{"EV_NO_SK_BALANCE": "1"}, {"EV_CONV_BALANCE_W": "1", "EV_BAL5": "64"}, {"EV_FUSE_ATTN": "0", "EV_SK_WGS": "3"}, {"EV_SPLIT": "0"}]):
         got = _run(tmp_path, f"b64_v{i}", extra, "b64")
         dmel = float((got["mel"] - ref["mel"]).abs().max())
         dwav = float((got["wav"] - ref["wav"]).abs().max())

@@ -58,15 +58,24 @@ __global__ void prod_kernel(const float* A, const float* B, float* D, int K, int
 
 // ---- 3: rates
 template <int MODE>   // 0: fp32 MFMA, 1: pure bf16 MFMA, 2: fed bf16 loop (LDS + buffer loads), 3: fed loop with bigger wave tile (2 x 4)
-__global__ __launch_bounds__(256) void rate_kernel(const float* W, float* out, int iters) {
+__global__ __launch_bounds__(256) void rate_kernel(const float* W, float* out, int iters, int data, unsigned long long* clk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 8192; i += 256) smem[i] = (float)(i & 7) * 0.125f;
+    // data 0: small constants; 1: what the split pieces of N(0,1) activations look like (two bf16 per word: random sign, exponent 120..127,
+    // random 7-bit mantissa); 2: random bits
+    for (int i = tid; i < 8192; i += 256) {
+        unsigned hsh = (unsigned)i * 2654435761u; hsh ^= hsh >> 15; hsh *= 2246822519u; hsh ^= hsh >> 13;
+        unsigned lo = ((hsh & 1) << 15) | ((120 + ((hsh >> 1) & 7)) << 7) | ((hsh >> 4) & 127);
+        unsigned hi = (((hsh >> 11) & 1) << 15) | ((120 + ((hsh >> 12) & 7)) << 7) | ((hsh >> 15) & 127);
+        smem[i] = data == 0 ? (float)(i & 7) * 0.125f : data == 1 ? __uint_as_float(lo | (hi << 16)) : __uint_as_float(hsh & 0x7f7f7f7fu);
+    }
     __syncthreads();
+    unsigned long long c0 = 0, r0 = 0;
+    if (blockIdx.x == 0 && tid == 0) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     f32x16 acc[8];
     for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     if (MODE == 0) {
-        float a = smem[lane], b = smem[lane + 64];
+        float a = data ? __uint_as_float(__float_as_uint(smem[lane]) << 16) : smem[lane], b = data ? __uint_as_float(__float_as_uint(smem[lane + 64]) & 0xffff0000u) : smem[lane + 64];
         for (int it = 0; it < iters; ++it)
 #pragma unroll
             for (int t = 0; t < 8; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
@@ -110,19 +119,23 @@ __global__ __launch_bounds__(256) void rate_kernel(const float* W, float* out, i
     float s = 0.f;
     for (int t = 0; t < 8; ++t) for (int r = 0; r < 16; ++r) s += acc[t][r];
     if (s == 12345.678f) out[0] = s;
+    if (blockIdx.x == 0 && tid == 0) { clk[0] = __builtin_amdgcn_s_memtime() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
-template <int MODE> static void rate(const char* name, const float* W, float* out, int wgs_per_cu, double mfma_per_iter, double flop_per_mfma, double alg_div) {
-    const int iters = 2000, grid = 256 * wgs_per_cu;
+template <int MODE> static void rate(const char* name, const float* W, float* out, int wgs_per_cu, double mfma_per_iter, double flop_per_mfma, double alg_div, int data) {
+    const int iters = 20000, grid = 256 * wgs_per_cu;
+    static unsigned long long* clk = nullptr;
+    if (!clk) CHK(hipHostMalloc((void**)&clk, 64));
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(grid), dim3(256), 32768, 0, W, out, iters);
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(grid), dim3(256), 32768, 0, W, out, iters, data, clk);
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0));
-    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(grid), dim3(256), 32768, 0, W, out, iters);
+    hipLaunchKernelGGL(rate_kernel<MODE>, dim3(grid), dim3(256), 32768, 0, W, out, iters, data, clk);
     CHK(hipEventRecord(e1)); CHK(hipEventSynchronize(e1));
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
     const double fl = (double)grid * 4 * iters * mfma_per_iter * flop_per_mfma;
-    printf("  %-46s %d wave(s)/SIMD: %7.3f ms  executed %7.1f TFLOP/s  = %6.1f TFLOP/s of fp32-equivalent work\n", name, wgs_per_cu, ms, fl / ms * 1e-9, fl / alg_div / ms * 1e-9);
+    printf("  %-46s data %d, %d wave(s)/SIMD: %7.3f ms  executed %7.1f TFLOP/s  = %6.1f TFLOP/s of fp32-equivalent work   (s_memtime / s_memrealtime = %.3f)\n", name, data, wgs_per_cu, ms,
+           fl / ms * 1e-9, fl / alg_div / ms * 1e-9, (double)clk[0] / (double)clk[1]);
 }
 
 int main() {
@@ -175,13 +188,21 @@ int main() {
     }
     // ---- 3: rates
     {
-        float *W, *out; CHK(hipMalloc(&W, 2 << 20)); CHK(hipMemset(W, 0, 2 << 20)); CHK(hipMalloc(&out, 64));
+        float *W, *out; CHK(hipMalloc(&W, 2 << 20)); CHK(hipMalloc(&out, 64));
+        {   // weight stand-ins: bf16 pairs with a random sign, exponent 116..123 and random mantissa
+            std::vector<unsigned> hw((2 << 20) / 4);
+            unsigned x = 12345u;
+            for (auto& v : hw) { x = x * 1664525u + 1013904223u; unsigned a = ((x >> 3) & 0x8000u) | ((116 + ((x >> 8) & 7)) << 7) | ((x >> 12) & 127); x = x * 1664525u + 1013904223u;
+                                 unsigned b = ((x >> 3) & 0x8000u) | ((116 + ((x >> 8) & 7)) << 7) | ((x >> 12) & 127); v = a | (b << 16); }
+            CHK(hipMemcpy(W, hw.data(), 2 << 20, hipMemcpyHostToDevice));
+        }
         printf("rates (256 CUs, 2000 iterations per wave):\n");
+        for (int data = 0; data < 3; ++data)
         for (int w = 1; w <= 2; ++w) {
-            rate<0>("fp32 v_mfma_f32_32x32x2_f32", W, out, w, 8, 4096.0, 1.0);
-            rate<1>("bf16 v_mfma_f32_32x32x16_bf16 (pure)", W, out, w, 8, 32768.0, 6.0);
-            rate<2>("6-product split, 64x64 wave tile, LDS + L2 fed", W, out, w, 24, 32768.0, 6.0);
-            rate<3>("6-product split, 64x128 wave tile, LDS + L2 fed", W, out, w, 48, 32768.0, 6.0);
+            rate<0>("fp32 v_mfma_f32_32x32x2_f32", W, out, w, 8, 4096.0, 1.0, data);
+            rate<1>("bf16 v_mfma_f32_32x32x16_bf16 (pure)", W, out, w, 8, 32768.0, 6.0, data);
+            rate<2>("6-product split, 64x64 wave tile, LDS + L2 fed", W, out, w, 24, 32768.0, 6.0, data);
+            rate<3>("6-product split, 64x128 wave tile, LDS + L2 fed", W, out, w, 48, 32768.0, 6.0, data);
         }
     }
     return 0;
