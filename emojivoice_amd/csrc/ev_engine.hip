@@ -958,7 +958,68 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
         return fail(h, "launch_mlp: second linear must be %d -> 256 with bias", L1.Cout);
     if ((double)g.nrows * std::max(ldy, 256) * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
     if (g.S < 4 && g.nrows > 1) return fail(h, "launch_mlp: utterance stride %d < 4 rows is not supported by the lean row walk", g.S);
-    const int ntiles = (g.nrows + 31) / 32, nchunk = L1.Mpad / 128;
+    const int nchunk = L1.Mpad / 128;
+    {   // the feed-forward of a large batch on the bf16 pipe: 64-row tiles, one persistent workgroup per CU (ln_mlp_split_kernel)
+        static const int split_terms = getenv("EV_SPLIT") ? atoi(getenv("EV_SPLIT")) : 6;
+        static const bool no_mlp_split = getenv("EV_NO_MLP_SPLIT") != nullptr;
+        const int nt64 = (g.nrows + 63) / 64;
+        if (mode == 0 && split_terms == 6 && !no_mlp_split && L1.Wx && L2->Wx && h->sk_balance && h->ncu > 0 && h->ncu <= EV_SK_MAXWG && nt64 >= h->ncu) {
+            if (ensure_sk(h)) return 1;
+            const long U = (long)nt64 * nchunk;
+            const int grid = h->ncu;
+            mp.W1x = L1.Wx; mp.W2x = L2->Wx; mp.ntiles = nt64;
+            mp.sk.q = (int)(U / grid); mp.sk.r = (int)(U % grid); mp.sk.spin_limit = h->sk_spin;
+            mp.sk.ctrl = h->sk_ctrl; mp.sk.flags = h->sk_ctrl + 16; mp.sk.part = h->sk_part; mp.sk.part_floats = EV_SK_PART_FLOATS;
+            if (L1.Mpad > 1024) return fail(h, "launch_mlp: hidden width %d > 1024 (LDS table of the SnakeBeta vectors)", L1.Mpad);
+            const size_t smem = (size_t)64 * (6 * 256 + 16) + (size_t)64 * (6 * 128 + 16) + 16 + (size_t)2 * L1.Mpad * sizeof(float);
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->prof) {
+                if (h->ev_used + 2 > h->ev_pool.size()) {
+                    for (int i = 0; i < 64; ++i) { hipEvent_t ev; HIPCHK(h, hipEventCreate(&ev)); h->ev_pool.push_back(ev); }
+                }
+                e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
+                HIPCHK(h, hipEventRecord(e0, h->stream));
+            }
+            ensure_dyn_smem<ln_mlp_split_kernel<6>>(smem, h->device);
+            static const char* stamp_file = getenv("EV_MLP_STAMPS");     // diagnostic: phase stamps of a few workgroups of the first launches
+            static int stamped = 0;
+            if (stamp_file && *stamp_file && stamped < 2) {
+                unsigned long long* d = nullptr;
+                HIPCHK(h, hipMalloc((void**)&d, (size_t)grid * 32 * sizeof(unsigned long long)));
+                HIPCHK(h, hipMemsetAsync(d, 0, (size_t)grid * 32 * sizeof(unsigned long long), h->stream));
+                mp.ep.stamps = d;
+                hipLaunchKernelGGL((ln_mlp_split_kernel<6>), dim3(grid), dim3(256), smem, h->stream, mp);
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                std::vector<unsigned long long> st((size_t)grid * 32);
+                HIPCHK(h, hipMemcpy(st.data(), d, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                hipFree(d);
+                mp.ep.stamps = nullptr;
+                if (FILE* f = fopen(stamp_file, "a")) {
+                    fprintf(f, "## ln_mlp_split_kernel rows=%d: %d workgroups, q=%d r=%d; per workgroup: us between consecutive stamps (start | staged+LN | per chunk: phase 1 | phase 2 + SnakeBeta | planes written ...)\n", g.nrows, grid, mp.sk.q, mp.sk.r);
+                    for (int w : {0, 1, 100, 255}) {
+                        if (w >= grid) continue;
+                        fprintf(f, "  wg %3d:", w);
+                        for (int k = 1; k < 32 && st[(size_t)w * 32 + k]; ++k) fprintf(f, " %.2f", (double)(st[(size_t)w * 32 + k] - st[(size_t)w * 32 + k - 1]) / 100.0);
+                        fprintf(f, "\n");
+                    }
+                    fclose(f);
+                }
+                ++stamped;
+            } else
+            hipLaunchKernelGGL((ln_mlp_split_kernel<6>), dim3(grid), dim3(256), smem, h->stream, mp);
+            HIPCHK(h, hipGetLastError());
+            if (h->prof) {
+                HIPCHK(h, hipEventRecord(e1, h->stream));
+                const double valid_rows = (double)(g.nrows / g.S) * g.T;
+                const double fl = 2.0 * (L1.macs_per_row + L2->macs_per_row) * valid_rows;
+                h->prof_flops += fl;
+                h->prof_launches += 1;
+                h->prof_recs.push_back({2, 256, Lout.Cout, 1, g.nrows, 120, 1, fl});
+            }
+            return 0;
+        }
+    }
+    const int ntiles = (g.nrows + 31) / 32;
     size_t smem = (size_t)(32 * 260 + 4 * 32 * 36 + 4) * sizeof(float);
     // Balanced persistent grid (SkCtl): three workgroups per CU — the LDS request is padded so that exactly three fit, i.e. every
     // CU holds the same number of them — each taking an equal share of the (tile, 128-wide chunk) units.  From one tile per CU up;
@@ -2310,7 +2371,7 @@ int ev_profile_read_split(ev_handle* h, double* ms_out, double* flops_out, int64
     if (h->prof_recs.size() * 2 == h->ev_used)
         for (size_t i = 0; i < h->prof_recs.size(); ++i) {
             const auto& r = h->prof_recs[i];
-            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140);
+            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && r.cfg == 120);
             if (!split) continue;
             float t = 0;
             HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));
