@@ -39,6 +39,7 @@ struct ConvLayer {
     int* nact[3] = {nullptr, nullptr, nullptr};       // per-tile active tap count (null when dense)
     unsigned char nact64[16] = {0};                   // host copy of the BM = 64 counts of the first 16 M tiles (unit weights of the balanced build)
     bool sparse_taps = false;
+    bool tile128_exact = true;              // every 128-channel M tile carries exactly the taps of both its 64-channel halves (no union waste)
     int kstack_mt = 0, kstack_tap = 0;      // sparse_taps of the stacked [k-tap conv | 1x1 conv] kind: 32-channel tiles >= kstack_mt carry only tap kstack_tap
     int ntaps = 0, off[EV_MAX_TAPS] = {0};
     int halo_lo = 0, halo_hi = 0;
@@ -260,6 +261,10 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                 else if (t * BM < L.Cout) L.sparse_taps = true;
             }
     }
+    L.tile128_exact = true;
+    for (int t = 0; t < L.Mpad / 128 && t * 128 < L.Cout; ++t)
+        for (int hh = 0; hh < 2; ++hh)
+            if ((2 * t + hh) * 64 < L.Cout && lists[1][2 * t + hh].size() != lists[0][t].size()) L.tile128_exact = false;
     if (L.sparse_taps) {   // the stacked pattern on the 32-channel tiling: full tiles first, then tiles with one and the same tap
         const int mt = (L.Cout + 31) / 32;
         int split = 0;
@@ -467,7 +472,12 @@ template <int BM, int BN, int WM, int WN, int TERMS = 6>
 void launch_split(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     const size_t xs = (size_t)(BN + ((lo.halo + 7) & ~7)) * EVX_RSB;
     constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4) * sizeof(float);
-    const size_t smem = xs > es ? xs : es;
+    size_t smem = xs > es ? xs : es;
+    {   // A/B: EV_SPLIT_WPC=<n> caps the deep-grid split builds at n workgroups per CU by padding the LDS request, which leaves the rest of
+        // the CU (LDS and registers) to the kernels of another stream
+        static const int wpc = getenv("EV_SPLIT_WPC") ? atoi(getenv("EV_SPLIT_WPC")) : 0;
+        if (wpc > 0) smem = std::max(smem, (size_t)((160 * 1024 / (wpc + 1) + 1024) & ~255));
+    }
     const dim3 grid(p.mtiles * p.ntiles);
     if (p.act == ACT_SNAKE) { ensure_dyn_smem<conv_split_kernel<BM, BN, WM, WN, 2, TERMS>>(smem, lo.device); hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, 2, TERMS>), grid, dim3(256), smem, st, p); }
     else if (lean_acc(p)) { ensure_dyn_smem<conv_split_kernel<BM, BN, WM, WN, 3, TERMS>>(smem, lo.device); hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, 3, TERMS>), grid, dim3(256), smem, st, p); }
@@ -678,10 +688,15 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     }
     {   // deep grids of dense-channel layers: the bf16-split build (EV_SPLIT=0: fp32 MFMA everywhere; 3 / 9: products per element pair, A/B)
         static const int split_terms = getenv("EV_SPLIT") ? atoi(getenv("EV_SPLIT")) : 6;
-        // (polyphase transposed convs keep the fp32 build: their 64-channel M tiles carry different tap subsets, a 128-channel tile the union)
+        // (polyphase transposed convs whose 64-channel M tiles carry different tap subsets — a 128-channel tile would compute the union — take
+        // the 64 x 128 tile below)
         const long nwg128 = (long)(L.Mpad / 128) * ((g.nrows + 127) / 128);
-        if (split_terms > 0 && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && !L.sparse_taps && nwg128 >= 2L * 2 * h->ncu && h->ncu > 0)
+        if (split_terms > 0 && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && L.Cout % 128 == 0 && (!L.sparse_taps || (L.tile128_exact && L.kstack_mt == 0)) && nwg128 >= 2L * 2 * h->ncu && h->ncu > 0)
             cfg = split_terms == 3 ? 43 : split_terms == 9 ? 49 : 40;
+        // polyphase transposed convs (M tiles of 64 channels with different tap subsets) on deep grids: 64 x 128 tiles of the split build
+        else if (split_terms == 6 && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && L.Cout % 64 == 0 && L.kstack_mt == 0 && h->ncu > 0 &&
+                 (L.sparse_taps || L.Cout % 128 != 0) &&
+                 (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) >= 2L * 3 * h->ncu) cfg = 41;
         // launches of a few rounds (the U-Net convs of a large-batch decode): the balanced persistent grid of the split build
         else if (split_terms == 6 && (cfg == 1 || cfg == 5 || cfg == 6 || cfg == 0) && L.Cout == L.Mpad && split_bal_ok(h, L, p, nwg128, 2)) cfg = 60;
     }
@@ -713,7 +728,11 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         static const char* senv = getenv("EV_STAGGER");
         if (senv && *senv) p.stagger_slots = atoi(senv) ? p.stagger_slots : 0;
     }
-    if ((cfg == 40 || cfg == 43 || cfg == 49 || cfg == 60) && !split_ok(L, p)) cfg = 0;
+    if ((cfg == 40 || cfg == 41 || cfg == 43 || cfg == 49 || cfg == 60) && !split_ok(L, p)) cfg = 0;
+    if (cfg == 41) {   // 64 x 128 on the bf16 pipe (per-tile tap lists of the 64-channel tiling)
+        p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_split<64, 128, 2, 2, 6>(p, h->stream, lo);
+    } else
     if (cfg == 60) {   // 128 x 128 on the bf16 pipe, balanced persistent grid
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         if (launch_split_bal<128, 128, 2, 2>(h, p, lo, 2)) return 1;
@@ -849,7 +868,11 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         if (C != 32 && C != 64 && C != 128) return fail(h, "launch_pair: C must be 32, 64 or 128");
         pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
         const size_t xs = (size_t)(NT + ((2 * pp.h1 + 7) & ~7)) * RSB, ys = (size_t)(NT + 16) * RSB, es = (size_t)4 * 32 * 36 * sizeof(float);
-        const size_t smem = std::max(xs, std::max(ys, es));
+        size_t smem = std::max(xs, std::max(ys, es));
+        {
+            static const int wpc = getenv("EV_SPLIT_WPC") ? atoi(getenv("EV_SPLIT_WPC")) : 0;
+            if (wpc > 0) smem = std::max(smem, (size_t)((160 * 1024 / (wpc + 1) + 1024) & ~255));
+        }
         const dim3 grid(p.ntiles);
 #define EV_PAIR_SPLIT(WM, WN) do { \
             if (lean == 1) { ensure_dyn_smem<resblock_pair_split_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_split_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, pp); } \
@@ -2371,7 +2394,7 @@ int ev_profile_read_split(ev_handle* h, double* ms_out, double* flops_out, int64
     if (h->prof_recs.size() * 2 == h->ev_used)
         for (size_t i = 0; i < h->prof_recs.size(); ++i) {
             const auto& r = h->prof_recs[i];
-            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && r.cfg == 120);
+            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && r.cfg == 120);
             if (!split) continue;
             float t = 0;
             HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));

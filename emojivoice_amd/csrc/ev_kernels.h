@@ -2887,7 +2887,13 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_split_kernel(const MlpParams mp
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) dst[pc] = ev_bload4(rs, wlane, off + (unsigned)(pc * 1024));
     };
-    for (int i = tid; i < mp.M1; i += 256) { Sv[i] = mp.alpha[i]; Sv[mp.M1 + i] = mp.binv[i]; }   // (published by the first staging barrier)
+    {   // (all loads first: one latency episode; published by the first staging barrier)
+        float va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = q * 256 + tid; va[q] = i < mp.M1 ? mp.alpha[i] : 0.f; vb[q] = i < mp.M1 ? mp.binv[i] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = q * 256 + tid; if (i < mp.M1) { Sv[i] = va[q]; Sv[mp.M1 + i] = vb[q]; } }
+    }
     const unsigned coff = (unsigned)(4 * lh) * 4u;
     const char* xrow = Xb + li * XRS + 16 * lh;
     const char* hrow = Hb + li * HRS + 16 * lh;
@@ -2920,22 +2926,19 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_split_kernel(const MlpParams mp
         ev_lds_barrier();                              // the previous segment's epilogue is done with its LDS slabs
         {   // ---- stage + LayerNorm + split: wave w owns rows 16 w .. 16 w + 15, a row = 4 channels per lane
             const f32x4 gm = *(const f32x4*)(mp.ln_g + lane * 4), be = *(const f32x4*)(mp.ln_b + lane * 4);
+            f32x4 xv[16];                               // all sixteen rows requested at once: one latency episode
 #pragma unroll
-            for (int h8 = 0; h8 < 2; ++h8) {
-                f32x4 xv[8];
+            for (int r = 0; r < 16; ++r) {
+                const int gr = n0 + wave * 16 + r;
+                xv[r] = ev_bload4(rX, ((unsigned)(gr < p.nrows ? gr : 0) * mp.ldx + lane * 4) * 4u, 0);   // (beyond the tensor: pad row 0)
+            }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int gr = n0 + wave * 16 + h8 * 8 + r;
-                    xv[r] = ev_bload4(rX, ((unsigned)(gr < p.nrows ? gr : 0) * mp.ldx + lane * 4) * 4u, 0);   // (beyond the tensor: pad row 0)
-                }
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const f32x4 o = ev_ln256_row(xv[r], gm, be, mp.ln_eps);
-                    uint2 q0v, q1v, q2v;
-                    evx_split4(o, q0v, q1v, q2v);
-                    char* dst = Xb + (wave * 16 + h8 * 8 + r) * XRS + lane * 8;
-                    *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v; *(uint2*)(dst + 4 * C) = q2v;
-                }
+            for (int r = 0; r < 16; ++r) {
+                const f32x4 o = ev_ln256_row(xv[r], gm, be, mp.ln_eps);
+                uint2 q0v, q1v, q2v;
+                evx_split4(o, q0v, q1v, q2v);
+                char* dst = Xb + (wave * 16 + r) * XRS + lane * 8;
+                *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v; *(uint2*)(dst + 4 * C) = q2v;
             }
         }
         if (pend_pub) { sk_publish(mp.sk, g, tag, tid); pend_pub = false; }   // (drain + barrier + flag: the barrier also publishes the staged rows)

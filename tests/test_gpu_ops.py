@@ -124,6 +124,20 @@ def test_conv_transpose1d(eng, B, Cin, T, Cout, K, s, p):
     _close(got, ref, what=f"convT {Cin}->{Cout} k{K} s{s}")
 
 
+def test_conv_transpose1d_split_build(eng):
+    """A polyphase transposed conv on a deep grid takes the 64 x 128 tile of the bf16-split build (cfg 41: the two phases' 64-channel
+    M tiles carry different tap subsets)."""
+    g = torch.Generator().manual_seed(11)
+    B, Cin, T, Cout, K, s, p = 3, 128, 33000, 64, 4, 2, 1
+    x = torch.randn(B, Cin, T, generator=g)
+    w = torch.randn(Cin, Cout, K, generator=g) / (Cin * K / s) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=p)
+    got = eng.op_conv1d(x.cuda(), w, b, transposed=True, stride=s, padding=p, pre_lrelu_slope=0.1)
+    assert eng.last_cfg() == 41, eng.last_cfg()
+    _close(got, ref, what="convT 128->64 k4 s2, split build")
+
+
 def test_conv_stride2(eng):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 256, 68, generator=g)
