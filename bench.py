@@ -568,7 +568,7 @@ def main():
             ach_split = sp_fl / (sp_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach_split, 2), "peak": round(peak_split, 1), "unit": "TFLOP/s", "frac": round(ach_split / peak_split, 4),
                         "traffic": traffic,
-                        "kernel": "conv_split_kernel + conv_split_bal_kernel + resblock_pair_split_kernel (fp32 contractions as 6 exact bf16 products per element "
+                        "kernel": "conv_split_kernel + conv_split_bal_kernel + resblock_pair_split_kernel + ln_mlp_split_kernel (fp32 contractions as 6 exact bf16 products per element "
                                   "pair on v_mfma_f32_32x32x16_bf16, fp32 accumulation)",
                         "peak_note": "2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 multiply-add; `achieved` counts ALGORITHMIC fp32 FLOP",
                         "executed_tflops": round(ach_split * SPLIT_PRODUCTS, 1), "peak_executed": PEAK_BF16_MFMA_TFLOPS,
