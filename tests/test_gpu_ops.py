@@ -246,10 +246,12 @@ def _ln_mlp_case(rows, M1, seed):
     return x, ln_g, ln_b, w1, b1, alpha, beta, w2, b2, mask
 
 
-@pytest.mark.parametrize("rows", [8192 + 808, 16640, 33280])
+@pytest.mark.parametrize("rows", [8192 + 808, 16640, 20011, 33280])
 def test_ln_mlp_balanced_grid(eng, rows, monkeypatch):
     """From one 32-row tile per CU up, ln_mlp_kernel runs as a balanced persistent grid (SkCtl in ev_kernels.h): row tiles are
-    split between workgroups along the hidden width and the partial tiles handed over inside the launch.  Checked against plain
+    split between workgroups along the hidden width and the partial tiles handed over inside the launch.  From one 64-row tile per CU
+    up (the last three cases; 20011 rows end in a partial tile) the feed-forward takes ln_mlp_split_kernel: the same grid logic around
+    the bf16-split products (six exact bf16 products per fp32 product, fp32 accumulation).  Checked against plain
     torch fp32, against a second handle whose owners never wait (EV_SK_SPIN=0: every hand-off takes the recompute path, which must
     deliver the SAME bits), and launch after launch (the flags carry a device-side epoch, nothing is re-zeroed)."""
     from emojivoice_amd._lib import Engine
