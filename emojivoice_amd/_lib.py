@@ -22,7 +22,7 @@ EXPORTS = [
     "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder", "ev_load_text_encoder", "ev_text_encoder",
     "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read", "ev_profile_read_split", "ev_dbg_last_cfg",
-    "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_attention", "ev_op_ln_mlp", "ev_set_mrf_streams_max",
+    "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_split_pieces", "ev_op_attention", "ev_op_ln_mlp", "ev_set_mrf_streams_max",
     "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out",
 ]
 
@@ -102,6 +102,7 @@ def load_library() -> C.CDLL:
     lib.ev_op_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
     lib.ev_op_groupnorm_mish.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ev_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.ev_op_split_pieces.argtypes = [vp, vp, i32, vp, vp]
     lib.ev_op_attention.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp]
     lib.ev_op_attn_out.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp, vp]
     lib.ev_op_ln_mlp.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp]
@@ -319,6 +320,13 @@ class Engine:
     # ---- profiling hooks (bench.py) -------------------------------------------
     def profile_enable(self, on: bool):
         self._check(self.lib.ev_profile_enable(self.h, int(on)), "ev_profile_enable")
+
+    def op_split_pieces(self, x):
+        """(3, n) fp32: the three bf16 pieces of every element of x, as the split builds' staging code cuts them."""
+        x = self._f32(x).reshape(-1)
+        out = torch.empty((3, x.numel()), dtype=torch.float32, device=x.device)
+        self._check(self.lib.ev_op_split_pieces(self.h, x.data_ptr(), x.numel(), out.data_ptr(), _stream_ptr()), "ev_op_split_pieces")
+        return out
 
     def last_cfg(self) -> int:
         return int(self.lib.ev_dbg_last_cfg(self.h))

@@ -235,6 +235,7 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                             const float r1 = w - fl(p0);
                             const unsigned p1 = bits(r1) & 0xffff0000u;
                             const unsigned p2 = bits(r1 - fl(p1)) & 0xffff0000u;
+                            if (fl(p0) + fl(p1) + fl(p2) != w && w == w) return fail(h, "weight %g is not the exact sum of three bf16 pieces (non-finite or subnormal?)", (double)w);
                             const size_t base = ((((size_t)tap * MT32 + mt) * KG16 + kg) * 3) * 512 + (size_t)lane * 8 + e;
                             Wx[base] = (unsigned short)(p0 >> 16); Wx[base + 512] = (unsigned short)(p1 >> 16); Wx[base + 1024] = (unsigned short)(p2 >> 16);
                         }
@@ -2560,6 +2561,14 @@ int ev_op_groupnorm_mish(ev_handle* h, const float* d_x, const float* d_gamma, c
     hipStreamSynchronize(h->stream);
     hipFree(X); hipFree(Y); hipFree(rm);
     return rc;
+}
+
+int ev_op_split_pieces(ev_handle* h, const float* d_x, int n, float* d_pieces, void* stream) {
+    if (!h || !d_x || !d_pieces || n <= 0) return fail(h, "ev_op_split_pieces: bad arguments");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(evx_split_check_kernel, dim3((n + 1023) / 1024), dim3(256), 0, (hipStream_t)stream, d_x, d_pieces, n);
+    HIPCHK(h, hipGetLastError());
+    return 0;
 }
 
 int ev_op_layernorm(ev_handle* h, const float* d_x, const float* d_gamma, const float* d_beta, int rows, int C, float* d_y, void* stream) {

@@ -810,6 +810,20 @@ __device__ __forceinline__ void evx_split4(const f32x4 v, uint2& q0, uint2& q1, 
     for (int e = 0; e < 4; ++e) u[e] = __float_as_uint(r[e] - __uint_as_float(w[e] & 0xffff0000u));
     q2.x = __builtin_amdgcn_perm(u[1], u[0], 0x07060302u); q2.y = __builtin_amdgcn_perm(u[3], u[2], 0x07060302u);
 }
+// test hook (ev_op_split_pieces): the three pieces of every element, as fp32 values, so that a test can check p0 + p1 + p2 == x bit for bit
+// and that each piece is a bf16 value
+__global__ void evx_split_check_kernel(const float* x, float* pieces /*[3][n]*/, int n) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    f32x4 v = {x[i], i + 1 < n ? x[i + 1] : 0.f, i + 2 < n ? x[i + 2] : 0.f, i + 3 < n ? x[i + 3] : 0.f};
+    uint2 q0, q1, q2;
+    evx_split4(v, q0, q1, q2);
+    const unsigned w[3][2] = {{q0.x, q0.y}, {q1.x, q1.y}, {q2.x, q2.y}};
+    for (int pc = 0; pc < 3; ++pc)
+        for (int e = 0; e < 4; ++e)
+            if (i + e < n) pieces[(size_t)pc * n + i + e] = __uint_as_float(((w[pc][e >> 1] >> (16 * (e & 1))) & 0xffffu) << 16);
+}
+
 template <int TM, int TN, int TERMS>
 __device__ __forceinline__ void evx_mma(f32x16 (&acc)[TM][TN], const f32x4 (&a)[3][TM], const f32x4 (&b)[3][TN]) {
     // smallest products first; the accumulators of the TM x TN tiles alternate, so consecutive MFMAs are independent

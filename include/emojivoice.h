@@ -189,6 +189,8 @@ int ev_op_conv1d(ev_handle *h, const float *d_x /*(B,Cin,T)*/, const float *w /*
                  int transposed, int stride, int padding, float pre_lrelu_slope /*<0: none*/, float *d_y, void *stream);
 int ev_op_groupnorm_mish(ev_handle *h, const float *d_x /*(B,C,T)*/, const float *d_gamma, const float *d_beta,
                          const int32_t *d_lengths, int B, int C, int T, int groups, float *d_y, void *stream);
+/* The three bf16 pieces (as fp32 values, (3, n)) the split builds cut every fp32 operand into: p0 + p1 + p2 == x exactly. */
+int ev_op_split_pieces(ev_handle *h, const float *d_x, int n, float *d_pieces, void *stream);
 int ev_op_layernorm(ev_handle *h, const float *d_x /*(rows,C)*/, const float *d_gamma, const float *d_beta, int rows,
                     int C, float *d_y, void *stream);
 /* ln_mlp_kernel: y = x + W2.SnakeBeta(W1.LN(x) + b1) + b2, rows * mask (mode 0; transformer.py:300-316) or y = W1.LN(x) [+ b1]

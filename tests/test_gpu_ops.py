@@ -55,6 +55,20 @@ def test_conv1d(eng, B, Cin, T, Cout, K, dil, slope):
     _close(got, ref, what=f"conv {Cin}->{Cout} k{K} d{dil}")
 
 
+def test_split_pieces_are_exact(eng):
+    """Every fp32 operand of the split builds is cut into three bf16 pieces whose sum is the operand, bit for bit — the products the
+    bf16 pipe forms are then exact products of exact pieces (values across the exponent range, signs, powers of two, zero)."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.cat([torch.randn(4096, generator=g) * 10.0 ** torch.randint(-20, 20, (4096,), generator=g).float(),
+                   torch.tensor([0.0, -0.0, 1.0, -1.0, 2.0 ** -100, 3.0e38, -3.0e38, 1.0 + 2.0 ** -23, 0.1, 65504.0, 1e-30])])
+    p = eng.op_split_pieces(x.cuda()).cpu()
+    assert torch.equal((p[0].double() + p[1].double() + p[2].double()).float(), x), "pieces do not sum to the operand"
+    assert torch.equal(p[0] + p[1] + p[2], x)                      # ... in fp32 arithmetic too (what the accumulator sees is exact)
+    bits = p.view(torch.int32)
+    assert int((bits & 0xFFFF).abs().max()) == 0, "a piece is not a bf16 value"
+    assert float((p[1].abs() - p[0].abs() * 2.0 ** -7).clamp(min=0).max()) == 0 and float((p[2].abs() - p[0].abs() * 2.0 ** -14).clamp(min=0).max()) == 0
+
+
 @pytest.mark.parametrize("B,Cin,T,Cout,K,dil,slope,cfg", [(5, 128, 30000, 128, 7, 3, 0.1, 40), (3, 256, 23000, 256, 11, 5, 0.1, 40), (2, 128, 40000, 256, 3, 1, -1.0, 40),
                                                           (16, 256, 600, 256, 3, 1, -1.0, 60), (40, 512, 258, 256, 1, 1, 0.1, 60)])
 def test_conv1d_split_builds(eng, B, Cin, T, Cout, K, dil, slope, cfg):
