@@ -28,12 +28,13 @@ g = torch.Generator().manual_seed(7)
 B, T = 3, 44
 if len(sys.argv) > 2 and sys.argv[2] == "b1": B, T = 1, 100
 if len(sys.argv) > 2 and sys.argv[2] == "b64": B, T = 64, 260
+if len(sys.argv) > 2 and sys.argv[2] == "b8": B, T = 8, 516
 m = MatchaTTS(W.synthetic_matcha_state(), device=dev)
 voc = Generator(AttrDict(v1)).to(dev); voc.load_state_dict(W.synthetic_hifigan_state())
 mu = torch.randn(B, 80, T, generator=g).to(dev); z = (torch.randn(B, 80, T, generator=g) * 0.667).to(dev)
 lengths = torch.tensor([44, 31, 17] if B == 3 else ([T] if B == 1 else [T - (7 * i) %% 90 for i in range(B)]), dtype=torch.int32).to(dev)
 spk = m._sd["spk_emb.weight"][(torch.arange(B, device=dev) * 4 + 1) %% 109]
-mel = m.engine.cfm_decode(mu, lengths, spk, z, 4 if B < 64 else 2, m.mel_std, m.mel_mean)
+mel = m.engine.cfm_decode(mu, lengths, spk, z, 4 if B < 8 else 2, m.mel_std, m.mel_mean)
 wav = voc(mel if B < 64 else mel[:4])
 torch.save({"mel": mel.cpu(), "wav": wav.cpu()}, sys.argv[1])
 """ % REPO
@@ -96,3 +97,14 @@ def test_batch64_balanced_builds(tmp_path):
         dmel = float((got["mel"] - ref["mel"]).abs().max())
         dwav = float((got["wav"] - ref["wav"]).abs().max())
         assert dmel <= 2e-5 and dwav <= 5e-5, (extra, dmel, dwav)
+
+
+def test_mid_batch_split_builds_agree_with_fp32_mfma(tmp_path):
+    """Batch 8 x 516 frames: the vocoder's C = 256 level is a few rounds of workgroups (conv_split_bal_kernel), its C = 128 level a deep
+    grid (conv_split_kernel), the C = 32 / 64 levels the fused split pairs; the U-Net keeps fp32-MFMA builds.  Against EV_SPLIT=0."""
+    ref = _run(tmp_path, "b8_fp32", {"EV_SPLIT": "0"}, "b8")
+    got = _run(tmp_path, "b8_split", {}, "b8")
+    assert got["wav"].shape == (8, 1, 516 * 256) and float(ref["wav"].abs().max()) > 1e-3
+    dmel = float((got["mel"] - ref["mel"]).abs().max())
+    dwav = float((got["wav"] - ref["wav"]).abs().max())
+    assert dmel <= 2e-5 and dwav <= 5e-5, (dmel, dwav)
