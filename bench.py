@@ -650,6 +650,10 @@ def main():
             "config": {"workload": f"config2: batch {B} x {T}-frame (5.99 s) utterances per GPU, {n_ode} Euler steps + HiFi-GAN V1, 22.05 kHz",
                        "global_batch": B * world, "frames": T, "ode_steps": n_ode, "parallelism": f"dp{world}",
                        "collective": "all_gather(waveforms)" if world > 1 else "none",
+                       "arithmetic": "f32 tensors and f32 accumulation throughout; EV_SPLIT=0 -> every product on the f32 MFMA" if DTYPE == "f32" else
+                                     "f32 tensors and f32 accumulation throughout; deep layers: operand = exact sum of 3 bf16 pieces, product = the 6 piece products of "
+                                     "weight <= 2 (drops < 2^-24 |ab|); dot products of length 1408 vs fp64: max rel err 3.4e-6 (f32 FMA chain: 3.1e-6), "
+                                     "profiles/r03_bf16_split_probe.txt; parity_* below are measured on this run's timed output",
                        "batch_pipeline": "off" if pipe is None else f"cfm(i+1) || hifigan(i) on two streams, {len(pipes)} pipeline(s) in flight",
                        "memory": "off" if pipe is None else f"{len(pipes)} engine pairs resident per GPU, each its own weights (0.1 GB) + workspace "
                                  f"({round(model.engine.workspace_bytes(B, T, 0) / 1e9 + voc.engine.workspace_bytes(B, 0, T) / 1e9, 1)} GB at this shape)"},
