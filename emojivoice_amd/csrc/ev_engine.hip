@@ -736,7 +736,8 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     } else
     if (cfg == 60) {   // 128 x 128 on the bf16 pipe, balanced persistent grid
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        if (launch_split_bal<128, 128, 2, 2>(h, p, lo, 2)) return 1;
+        static const int bal_wgs = getenv("EV_SPLIT_BAL_WGS") ? atoi(getenv("EV_SPLIT_BAL_WGS")) : 2;    // A/B: persistent workgroups per CU (1 or 2)
+        if (launch_split_bal<128, 128, 2, 2>(h, p, lo, bal_wgs == 1 ? 1 : 2)) return 1;
     } else
     if (cfg == 40 || cfg == 43 || cfg == 49) {   // 128 x 128 on the bf16 pipe
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
