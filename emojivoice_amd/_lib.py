@@ -21,7 +21,7 @@ CSRC = os.path.join(_HERE, "csrc")
 EXPORTS = [
     "ev_abi_version", "ev_create", "ev_destroy", "ev_last_error", "ev_load_estimator", "ev_load_vocoder", "ev_load_text_encoder", "ev_text_encoder",
     "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
-    "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read", "ev_profile_read_split", "ev_dbg_last_cfg",
+    "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read", "ev_profile_read_split", "ev_dbg_last_cfg", "ev_set_arithmetic", "ev_get_arithmetic",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_split_pieces", "ev_op_attention", "ev_op_ln_mlp", "ev_set_mrf_streams_max",
     "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out",
 ]
@@ -99,6 +99,8 @@ def load_library() -> C.CDLL:
     lib.ev_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     lib.ev_profile_read_split.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     lib.ev_dbg_last_cfg.argtypes = [vp]
+    lib.ev_set_arithmetic.argtypes = [vp, i32]
+    lib.ev_get_arithmetic.argtypes = [vp]
     lib.ev_op_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
     lib.ev_op_groupnorm_mish.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ev_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
@@ -327,6 +329,13 @@ class Engine:
         out = torch.empty((3, x.numel()), dtype=torch.float32, device=x.device)
         self._check(self.lib.ev_op_split_pieces(self.h, x.data_ptr(), x.numel(), out.data_ptr(), _stream_ptr()), "ev_op_split_pieces")
         return out
+
+    def set_arithmetic(self, bf16_products: int):
+        """6 (default): deep layers form each fp32 product from six exact bf16 products on the bf16 matrix pipe; 0: fp32 MFMA everywhere."""
+        self._check(self.lib.ev_set_arithmetic(self.h, int(bf16_products)), "ev_set_arithmetic")
+
+    def arithmetic(self) -> int:
+        return int(self.lib.ev_get_arithmetic(self.h))
 
     def last_cfg(self) -> int:
         return int(self.lib.ev_dbg_last_cfg(self.h))

@@ -149,6 +149,8 @@ struct ev_handle {
     int ncu = 0;                    // compute units of the device
     unsigned* sk_ctrl = nullptr;    // [0] epoch [1] arrivals [2] timed-out waits | flags from word 16 on
     float* sk_part = nullptr;
+    int split_terms = 6;            // bf16 products per fp32 product of the split builds (ev_set_arithmetic; EV_SPLIT presets it): 0 = fp32 MFMA
+                                    // everywhere, 6 = shipped; 3 / 9 = accuracy A/B of conv_split_kernel (the other split builds then run 6)
     int last_cfg = -1;              // build the last launch_conv / launch_pair took (ev_dbg_last_cfg: tests assert that a shape ran on the build they mean)
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
     bool sk_spread = false;         // EV_SK_SPREAD=1: launches of fewer row tiles than CUs (small batches) spread their units over up to 2 x CUs workgroups
@@ -688,7 +690,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         }
     }
     {   // deep grids of dense-channel layers: the bf16-split build (EV_SPLIT=0: fp32 MFMA everywhere; 3 / 9: products per element pair, A/B)
-        static const int split_terms = getenv("EV_SPLIT") ? atoi(getenv("EV_SPLIT")) : 6;
+        const int split_terms = h->split_terms;
         // (polyphase transposed convs whose 64-channel M tiles carry different tap subsets — a 128-channel tile would compute the union — take
         // the 64 x 128 tile below)
         const long nwg128 = (long)(L.Mpad / 128) * ((g.nrows + 127) / 128);
@@ -863,7 +865,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     }
     static const bool no_lean = getenv("EV_NO_LEAN") != nullptr;
     const int lean = no_lean ? 0 : ((e.accum || e.div3 || e.act2_lrelu) ? 3 : 1);
-    static const int split_terms = getenv("EV_SPLIT") ? atoi(getenv("EV_SPLIT")) : 6;
+    const int split_terms = h->split_terms;
     const bool split = split_terms > 0 && lean != 0 && L1.Wx && L2.Wx && !(e.force_cfg == 0);
     if (split) {   // the bf16-split build: LDS rows hold all C channels as three bf16 planes
         const int NT = C == 32 ? 256 : C == 64 ? 128 : 64, RSB = 6 * C + 16;
@@ -985,7 +987,7 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
     if (g.S < 4 && g.nrows > 1) return fail(h, "launch_mlp: utterance stride %d < 4 rows is not supported by the lean row walk", g.S);
     const int nchunk = L1.Mpad / 128;
     {   // the feed-forward of a large batch on the bf16 pipe: 64-row tiles, one persistent workgroup per CU (ln_mlp_split_kernel)
-        static const int split_terms = getenv("EV_SPLIT") ? atoi(getenv("EV_SPLIT")) : 6;
+        const int split_terms = h->split_terms;
         static const bool no_mlp_split = getenv("EV_NO_MLP_SPLIT") != nullptr;
         const int nt64 = (g.nrows + 63) / 64;
         if (mode == 0 && split_terms == 6 && !no_mlp_split && L1.Wx && L2->Wx && h->sk_balance && h->ncu > 0 && h->ncu <= EV_SK_MAXWG && nt64 >= h->ncu) {
@@ -1728,6 +1730,7 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     { const char* fp = getenv("EV_FUSE_ATTN"); if (fp && *fp == '0') h->fuse_attn = false; }
     { const char* fp = getenv("EV_FUSE_MLP_MIN"); if (fp && *fp) h->fuse_mlp_min_tiles = atoi(fp); }
     { const char* fp = getenv("EV_MRF_STREAMS_MAX"); if (fp && *fp) h->mrf_max_frames = atoi(fp); }
+    { const char* sp = getenv("EV_SPLIT"); if (sp && *sp) { const int t = atoi(sp); h->split_terms = (t == 0 || t == 3 || t == 6 || t == 9) ? t : 6; } }
     { const char* fp = getenv("EV_NO_SK_BALANCE"); if (fp && *fp && *fp != '0') h->sk_balance = false; }
     { const char* fp = getenv("EV_SK_SPIN"); if (fp && *fp) h->sk_spin = atoi(fp); }
     { const char* fp = getenv("EV_SK_WGS"); if (fp && *fp) h->sk_wgs = std::min(3, std::max(1, atoi(fp))); }
@@ -2385,6 +2388,16 @@ int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* 
 }
 
 int ev_dbg_last_cfg(ev_handle* h) { return h ? h->last_cfg : -1; }
+
+// Arithmetic of the deep layers' products: 6 (default) = every fp32 product from six exact bf16 x bf16 products on the bf16 matrix pipe,
+// 0 = every layer on the fp32 MFMA.  Takes effect with the next call on this handle; results of the two settings agree to fp32 rounding.
+int ev_set_arithmetic(ev_handle* h, int bf16_products) {
+    if (!h) return 1;
+    if (bf16_products != 0 && bf16_products != 3 && bf16_products != 6 && bf16_products != 9) return fail(h, "ev_set_arithmetic: 0, 3, 6 or 9 products, got %d", bf16_products);
+    h->split_terms = bf16_products;
+    return 0;
+}
+int ev_get_arithmetic(ev_handle* h) { return h ? h->split_terms : -1; }
 
 // The launches of the bf16-split builds (conv_split_kernel, conv_split_bal_kernel, resblock_pair_split_kernel) among those recorded
 // since the last reset: call before ev_profile_read(..., reset = 1).

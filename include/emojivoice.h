@@ -169,6 +169,16 @@ int ev_profile_read(ev_handle *h, double *conv_ms, double *conv_flops, int64_t *
  * resblock_pair_split_kernel: every fp32 product as six exact bf16 products, fp32 accumulation); call before a resetting
  * ev_profile_read.  The rest of the family runs on v_mfma_f32_32x32x2_f32. */
 int ev_profile_read_split(ev_handle *h, double *ms, double *flops, int64_t *launches);
+/* Arithmetic of the contractions.  Tensors are fp32 and every accumulation is fp32 in either setting.
+ *   6 (default): layers deep enough to pay for it form each fp32 product from six exact bf16 x bf16 products on the bf16 matrix pipe
+ *                (the operand is the exact sum of three bf16 pieces; what the six products leave out is below 2^-24 |a b|, one fp32
+ *                rounding) — errors indistinguishable from an fp32 FMA chain, ~1.45x the throughput at batch 64
+ *   0:           every layer on the fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain)
+ *   3 / 9:       accuracy A/B of conv_split_kernel only (tools/bf16_split_probe.hip)
+ * The environment variable EV_SPLIT presets it for handles created afterwards.  Takes effect with the next call on the handle. */
+int ev_set_arithmetic(ev_handle *h, int bf16_products);
+int ev_get_arithmetic(ev_handle *h);
+
 /* Test hook: the build the last conv / fused-pair launch of this handle took (tile configuration id: 40 / 60 = conv_split_kernel /
  * its balanced grid, 140 + taps = resblock_pair_split_kernel, 100 + taps = resblock_pair_kernel, others: see launch_conv). */
 int ev_dbg_last_cfg(ev_handle *h);

@@ -138,6 +138,29 @@ def test_conv_transpose1d(eng, B, Cin, T, Cout, K, s, p):
     _close(got, ref, what=f"convT {Cin}->{Cout} k{K} s{s}")
 
 
+def test_arithmetic_switch_in_process(eng):
+    """ev_set_arithmetic: the same handle, the same launch geometry, products on the bf16 pipe (6) or on the fp32 MFMA (0); the two agree to
+    fp32 rounding and each is bit-reproducible."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 128, 33000, generator=g)
+    w = torch.randn(128, 128, 7, generator=g) / (128 * 7) ** 0.5
+    b = torch.randn(128, generator=g)
+    assert eng.arithmetic() == 6
+    y6 = eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1)
+    assert eng.last_cfg() == 40
+    try:
+        eng.set_arithmetic(0)
+        y0 = eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1)
+        assert eng.last_cfg() not in (40, 41, 60)
+        assert torch.equal(eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1), y0)
+    finally:
+        eng.set_arithmetic(6)
+    _close(y6, y0, rtol=1e-5, what="bf16-split products vs fp32 MFMA")
+    assert torch.equal(eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1), y6)
+    with pytest.raises(Exception):
+        eng.set_arithmetic(4)
+
+
 def test_conv_transpose1d_split_build(eng):
     """A polyphase transposed conv on a deep grid takes the 64 x 128 tile of the bf16-split build (cfg 41: the two phases' 64-channel
     M tiles carry different tap subsets)."""
