@@ -161,6 +161,41 @@ def test_arithmetic_switch_in_process(eng):
         eng.set_arithmetic(4)
 
 
+def test_split_builds_match_fp32_mfma_on_random_shapes(eng):
+    """Differential test of the two datapaths on one handle: random layer shapes (channels, taps, dilations, odd lengths, ragged last tiles,
+    with and without the prologue leaky-relu) that land on conv_split_kernel (40), its 64-channel tile (41) or the balanced grid (60)."""
+    rng = torch.Generator().manual_seed(2024)
+    seen = set()
+    for case in range(14):
+        cin = [64, 128, 256, 512][int(torch.randint(0, 4, (1,), generator=rng))]
+        cout = [64, 128, 192, 256, 512][int(torch.randint(0, 5, (1,), generator=rng))]
+        K = [1, 3, 7, 11][int(torch.randint(0, 4, (1,), generator=rng))]
+        dil = [1, 3, 5][int(torch.randint(0, 3, (1,), generator=rng))] if K > 1 else 1
+        slope = 0.1 if case % 2 else -1.0
+        deep = case % 3 != 2                               # two of three cases on a deep grid, the third on a few rounds of workgroups
+        rows = ((220000 if cout < 128 else 170000 * 128 // cout) if deep else 20000) + int(torch.randint(0, 999, (1,), generator=rng))
+        B = 3
+        T = rows // B
+        x = torch.randn(B, cin, T, generator=rng)
+        w = torch.randn(cout, cin, K, generator=rng) / (cin * K) ** 0.5
+        b = torch.randn(cout, generator=rng)
+        pad = dil * (K - 1) // 2
+        y6 = eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope)
+        cfg = eng.last_cfg()
+        seen.add(cfg)
+        try:
+            eng.set_arithmetic(0)
+            y0 = eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope)
+            assert eng.last_cfg() not in (40, 41, 60)
+        finally:
+            eng.set_arithmetic(6)
+        if cfg in (40, 41, 60):
+            _close(y6, y0, rtol=1e-5, what=f"case {case}: {cin}->{cout} k{K} d{dil} T{T} cfg {cfg}")
+        else:
+            assert torch.equal(y6, y0), f"case {case}: both settings took the fp32 build {cfg} and must agree bit for bit"
+    assert {40, 41, 60} <= seen, f"the shapes were meant to cover all three split builds, saw {sorted(seen)}"
+
+
 def test_conv_transpose1d_split_build(eng):
     """A polyphase transposed conv on a deep grid takes the 64 x 128 tile of the bf16-split build (cfg 41: the two phases' 64-channel
     M tiles carry different tap subsets)."""
