@@ -117,6 +117,23 @@ def test_hifigan_vs_oracle(vocoder, voc_sd, B, T):
     assert float(ref.pow(2).mean().sqrt()) > 0.05
 
 
+@pytest.mark.parametrize("B,T", [(2, 777), (1, 1500)])
+def test_hifigan_arithmetic_switch(vocoder, B, T):
+    """The vocoder on one handle with its products on the bf16 pipe (default: fused split pairs at every level, split convs where the grid is
+    deep enough) and on the fp32 MFMA (ev_set_arithmetic 0): odd lengths, ragged last tiles; the two agree far inside the waveform gate."""
+    g = torch.Generator().manual_seed(T + B)
+    mel = (torch.randn(B, 80, T, generator=g) * 2.0 - 5.0).cuda()
+    w6 = vocoder(mel)
+    assert torch.equal(vocoder(mel), w6)
+    try:
+        vocoder.engine.set_arithmetic(0)
+        w0 = vocoder(mel)
+    finally:
+        vocoder.engine.set_arithmetic(6)
+    assert float(w0.abs().max()) > 1e-3
+    assert float((w6 - w0).abs().max()) <= 5e-5 and float((w6 - w0).pow(2).mean().sqrt()) <= WAV_RMS_GATE / 100
+
+
 def test_config2_shape_properties(model, vocoder):
     """Full-size (B=8 slice of config 2: T=516) size-independent checks: batch-row independence when nothing is
     padded (all lengths = Tp: no cross-utterance coupling left) and wav_len == 256 * mel_len (cli.py:310)."""
