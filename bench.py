@@ -288,6 +288,30 @@ def run_config5(args, device):
 # ---------------------------------------------------------------------------------------------------------------------
 # compact config-4 / config-5 records for the default line (so that the driver's own run carries them)
 # ---------------------------------------------------------------------------------------------------------------------
+def arithmetic_record(voc, mel):
+    """HiFi-GAN of the bench batch under the three settings of ev_set_arithmetic (6 = default = what `value` is measured with; 0 = every
+    layer on the fp32 MFMA; 3 = opt-in fast setting, NOT fp32-grade): ms per call and the waveform difference to the fp32-MFMA result."""
+    rec = {"note": "HiFi-GAN alone, serial, same mel; `value` above is measured with 6; 3 is an opt-in setting whose products carry ~16 significand bits"}
+    outs = {}
+    try:
+        for a in (0, 6, 3):
+            voc.engine.set_arithmetic(a)
+            w = voc(mel)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                w = voc(mel)
+            torch.cuda.synchronize()
+            outs[a] = w
+            rec[f"products_{a}"] = {"hifigan_ms": round((time.perf_counter() - t0) / 3 * 1e3, 2)}
+    finally:
+        voc.engine.set_arithmetic(6 if os.environ.get("EV_SPLIT") in (None, "", "6") else int(os.environ["EV_SPLIT"]))
+    for a in (6, 3):
+        d = outs[a] - outs[0]
+        rec[f"products_{a}"].update({"wav_rms_vs_fp32_mfma": float(d.pow(2).mean().sqrt()), "wav_linf_vs_fp32_mfma": float(d.abs().max())})
+    return rec
+
+
 def config4_record(sd, model, mu, z, spk, lengths, T):
     """ODE-step sweep at the bench batch (flow_matching.py:55-85): CFM decode ms at n in {2, 4, 10, 20, 50}, mel-MSE against the
     n = 50 output, and mel L-inf of ROW 0 against the CPU oracle at the same n."""
@@ -634,10 +658,14 @@ def main():
             cpu["parity_wav_rms"] = float((wav[:s].cpu() - ref_wav).pow(2).mean().sqrt())
             cpu["parity_wav_linf"] = float((wav[:s].cpu() - ref_wav).abs().max())
             cpu["parity_rows"] = f"rows 0..{s - 1} of the last timed step's output (batch {B})"
-        c4 = c5 = None
+        c4 = c5 = arith = None
         if world == 1 and not args.no_extras and B == 64 and T == 516:
             if pipe is not None:
                 pipe.close()                                    # (gives the vocoder engine its small-call three-stream fan-out back)
+            try:
+                arith = arithmetic_record(voc, mel)
+            except Exception as ex:  # noqa: BLE001
+                log(f"[bench] arithmetic record skipped: {type(ex).__name__}: {ex}")
             try:
                 c4 = config4_record(sd, model, mu, z, spk, lengths, T)
                 c5 = config5_record(model, voc)
@@ -662,7 +690,7 @@ def main():
             "serial_ms_per_step": round(serial_ms, 2), "batch_latency_ms": round(batch_latency_ms, 2), "stage_ms": stage_ms,
             "text_encoder": text_enc,
             "roofline": roofline, "path_roofline": path_roof, "cpu_baseline": cpu, "pcie_inclusive": pcie,
-            "config4": c4, "config5": c5,
+            "config4": c4, "config5": c5, "arithmetic_settings": arith,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

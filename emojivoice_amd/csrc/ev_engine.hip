@@ -150,7 +150,8 @@ struct ev_handle {
     unsigned* sk_ctrl = nullptr;    // [0] epoch [1] arrivals [2] timed-out waits | flags from word 16 on
     float* sk_part = nullptr;
     int split_terms = 6;            // bf16 products per fp32 product of the split builds (ev_set_arithmetic; EV_SPLIT presets it): 0 = fp32 MFMA
-                                    // everywhere, 6 = shipped; 3 / 9 = accuracy A/B of conv_split_kernel (the other split builds then run 6)
+                                    // everywhere, 6 = shipped, 3 = opt-in fast setting (conv_split_kernel and the fused pairs; not fp32-grade),
+                                    // 9 = accuracy A/B of conv_split_kernel
     int last_cfg = -1;              // build the last launch_conv / launch_pair took (ev_dbg_last_cfg: tests assert that a shape ran on the build they mean)
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
     bool sk_spread = false;         // EV_SK_SPREAD=1: launches of fewer row tiles than CUs (small batches) spread their units over up to 2 x CUs workgroups
@@ -697,7 +698,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         if (split_terms > 0 && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && L.Cout % 128 == 0 && (!L.sparse_taps || (L.tile128_exact && L.kstack_mt == 0)) && nwg128 >= 2L * 2 * h->ncu && h->ncu > 0)
             cfg = split_terms == 3 ? 43 : split_terms == 9 ? 49 : 40;
         // polyphase transposed convs (M tiles of 64 channels with different tap subsets) on deep grids: 64 x 128 tiles of the split build
-        else if (split_terms == 6 && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && L.Cout % 64 == 0 && L.kstack_mt == 0 && h->ncu > 0 &&
+        else if ((split_terms == 6 || split_terms == 3) && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && L.Cout % 64 == 0 && L.kstack_mt == 0 && h->ncu > 0 &&
                  (L.sparse_taps || L.Cout % 128 != 0) &&
                  (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) >= 2L * 3 * h->ncu) cfg = 41;
         // launches of a few rounds (the U-Net convs of a large-batch decode): the balanced persistent grid of the split build
@@ -734,7 +735,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     if ((cfg == 40 || cfg == 41 || cfg == 43 || cfg == 49 || cfg == 60) && !split_ok(L, p)) cfg = 0;
     if (cfg == 41) {   // 64 x 128 on the bf16 pipe (per-tile tap lists of the 64-channel tiling)
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        launch_split<64, 128, 2, 2, 6>(p, h->stream, lo);
+        if (h->split_terms == 3) launch_split<64, 128, 2, 2, 3>(p, h->stream, lo); else launch_split<64, 128, 2, 2, 6>(p, h->stream, lo);
     } else
     if (cfg == 60) {   // 128 x 128 on the bf16 pipe, balanced persistent grid
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
@@ -878,11 +879,13 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
             if (wpc > 0) smem = std::max(smem, (size_t)((160 * 1024 / (wpc + 1) + 1024) & ~255));
         }
         const dim3 grid(p.ntiles);
-#define EV_PAIR_SPLIT(WM, WN) do { \
-            if (lean == 1) { ensure_dyn_smem<resblock_pair_split_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_split_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, pp); } \
-            else { ensure_dyn_smem<resblock_pair_split_kernel<WM, WN, 3>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_split_kernel<WM, WN, 3>), grid, dim3(256), smem, h->stream, pp); } } while (0)
+#define EV_PAIR_SPLIT_T(WM, WN, TT) do { \
+            if (lean == 1) { ensure_dyn_smem<resblock_pair_split_kernel<WM, WN, 1, TT>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_split_kernel<WM, WN, 1, TT>), grid, dim3(256), smem, h->stream, pp); } \
+            else { ensure_dyn_smem<resblock_pair_split_kernel<WM, WN, 3, TT>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_split_kernel<WM, WN, 3, TT>), grid, dim3(256), smem, h->stream, pp); } } while (0)
+#define EV_PAIR_SPLIT(WM, WN) do { if (split_terms == 3) EV_PAIR_SPLIT_T(WM, WN, 3); else EV_PAIR_SPLIT_T(WM, WN, 6); } while (0)   // (9: the six-product build)
         if (C == 32) EV_PAIR_SPLIT(1, 4); else if (C == 64) EV_PAIR_SPLIT(2, 2); else EV_PAIR_SPLIT(4, 1);
 #undef EV_PAIR_SPLIT
+#undef EV_PAIR_SPLIT_T
     } else if (C == 32) {
         constexpr int NT = 256;
         pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;

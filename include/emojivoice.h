@@ -174,7 +174,11 @@ int ev_profile_read_split(ev_handle *h, double *ms, double *flops, int64_t *laun
  *                (the operand is the exact sum of three bf16 pieces; what the six products leave out is below 2^-24 |a b|, one fp32
  *                rounding) — errors indistinguishable from an fp32 FMA chain, ~1.45x the throughput at batch 64
  *   0:           every layer on the fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain)
- *   3 / 9:       accuracy A/B of conv_split_kernel only (tools/bf16_split_probe.hip)
+ *   3:           opt-in fast setting of the vocoder's deep layers (conv_split_kernel, resblock_pair_split_kernel): the three products
+ *                of weight <= 1, ~16 significand bits per product (dot products of length 1408: 8.9e-5 max relative error against
+ *                3.4e-6).  HiFi-GAN at batch 64: 61 ms against 97 (6) and 154 (0); waveform RMS difference to the fp32 MFMA result
+ *                7e-5 (6: 1.8e-6), i.e. inside the 1e-3 gate but NOT fp32-grade — never the default, never what bench.py times
+ *   9:           accuracy A/B of conv_split_kernel only (tools/bf16_split_probe.hip); the other split builds run 6
  * The environment variable EV_SPLIT presets it for handles created afterwards.  Takes effect with the next call on the handle. */
 int ev_set_arithmetic(ev_handle *h, int bf16_products);
 int ev_get_arithmetic(ev_handle *h);
