@@ -26,10 +26,15 @@ sys.path.insert(0, REPO)
 SR, HOP = 22050, 256
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
-SPLIT_PRODUCTS = 6              # bf16 x bf16 products per fp32 multiply-add of the split builds (conv_split_kernel)
-# fp32 in, fp32 out, fp32 accumulation everywhere; the deep conv layers form each fp32 product from six exact bf16 x bf16 products
-# (fp32-grade: tools/bf16_split_probe.hip), the rest runs on the fp32 MFMA.  EV_SPLIT=0 puts everything on the fp32 MFMA.
-DTYPE = "f32" if os.environ.get("EV_SPLIT") == "0" else "f32 (deep convs: each f32 product as 6 exact bf16 products on the bf16 MFMA, f32 accumulate)"
+ARITH = int(os.environ.get("EV_SPLIT") or 16)   # ev_set_arithmetic preset of the handles this process creates
+# products per fp32 multiply-add of the deep layers: 16 -> three fp16 x fp16 products of two block-scaled fp16 pieces (default), 6 / 3 / 9 ->
+# bf16 pieces; the U-Net feed-forward runs the six-product bf16 form under 16 too
+SPLIT_PRODUCTS = {16: 3, 6: 6, 3: 3, 9: 9}.get(ARITH, 3)
+# fp32 in, fp32 out, fp32 accumulation everywhere; the deep layers form each fp32 product from 16-bit pieces on the fp16 / bf16 matrix pipe
+# (fp32-grade: tools/arith_accuracy.py, tools/bf16_split_probe.hip), the rest runs on the fp32 MFMA.  EV_SPLIT=0: everything on the fp32 MFMA.
+DTYPE = ("f32" if ARITH == 0 else
+         "f32 (deep layers: operand = two block-scaled fp16 pieces, product = 3 fp16 products on the fp16 MFMA, f32 accumulate)" if ARITH == 16 else
+         f"f32 (deep layers: operand = three bf16 pieces, product = {SPLIT_PRODUCTS} bf16 products on the bf16 MFMA, f32 accumulate)")
 PEAK_HBM_GBS = 8000.0
 # SURVEY.md §8(d), measured on the reference modules: FLOPs and layer-granular activation bytes per 6-s utterance
 ALG_FLOP_PER_AUDIO_S = 62.5e9
@@ -289,12 +294,14 @@ def run_config5(args, device):
 # compact config-4 / config-5 records for the default line (so that the driver's own run carries them)
 # ---------------------------------------------------------------------------------------------------------------------
 def arithmetic_record(voc, mel):
-    """HiFi-GAN of the bench batch under the three settings of ev_set_arithmetic (6 = default = what `value` is measured with; 0 = every
-    layer on the fp32 MFMA; 3 = opt-in fast setting, NOT fp32-grade): ms per call and the waveform difference to the fp32-MFMA result."""
-    rec = {"note": "HiFi-GAN alone, serial, same mel; `value` above is measured with 6; 3 is an opt-in setting whose products carry ~16 significand bits"}
+    """HiFi-GAN of the bench batch under the settings of ev_set_arithmetic (16 = default = what `value` is measured with: two block-scaled
+    fp16 pieces, three products; 6 = three bf16 pieces, six products; 0 = every layer on the fp32 MFMA; 3 = opt-in fast bf16 setting, NOT
+    fp32-grade): ms per call and the waveform difference to the fp32-MFMA result."""
+    rec = {"note": "HiFi-GAN alone, serial, same mel; `value` above is measured with 16 unless EV_SPLIT says otherwise; 16 and 6 are fp32-grade, "
+                   "3 is an opt-in setting whose products carry ~16 significand bits"}
     outs = {}
     try:
-        for a in (0, 6, 3):
+        for a in (0, 16, 6, 3):
             voc.engine.set_arithmetic(a)
             w = voc(mel)
             torch.cuda.synchronize()
@@ -305,8 +312,8 @@ def arithmetic_record(voc, mel):
             outs[a] = w
             rec[f"products_{a}"] = {"hifigan_ms": round((time.perf_counter() - t0) / 3 * 1e3, 2)}
     finally:
-        voc.engine.set_arithmetic(6 if os.environ.get("EV_SPLIT") in (None, "", "6") else int(os.environ["EV_SPLIT"]))
-    for a in (6, 3):
+        voc.engine.set_arithmetic(ARITH)
+    for a in (16, 6, 3):
         d = outs[a] - outs[0]
         rec[f"products_{a}"].update({"wav_rms_vs_fp32_mfma": float(d.pow(2).mean().sqrt()), "wav_linf_vs_fp32_mfma": float(d.abs().max())})
     return rec
@@ -587,17 +594,21 @@ def main():
         # executed MFMA FLOP against the bf16 peak.  The launches still on v_mfma_f32_32x32x2_f32 are priced against the fp32 peak.
         sp_ms, sp_fl, sp_n = sp_c[0] + sp_v[0], sp_c[1] + sp_v[1], sp_c[2] + sp_v[2]
         f32_ms, f32_fl, f32_n = conv_ms - sp_ms, conv_fl - sp_fl, conv_n - sp_n
-        peak_split = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS
+        peak_split = PEAK_BF16_MFMA_TFLOPS / SPLIT_PRODUCTS      # (the fp16 MFMA has the bf16 MFMA's dense peak)
         if sp_n > 0:
             ach_split = sp_fl / (sp_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach_split, 2), "peak": round(peak_split, 1), "unit": "TFLOP/s", "frac": round(ach_split / peak_split, 4),
                         "traffic": traffic,
-                        "kernel": "conv_split_kernel + conv_split_bal_kernel + resblock_pair_split_kernel + ln_mlp_split_kernel (fp32 contractions as 6 exact bf16 products per element "
-                                  "pair on v_mfma_f32_32x32x16_bf16, fp32 accumulation)",
-                        "peak_note": "2500 TFLOP/s dense bf16 MFMA / 6 products per fp32 multiply-add; `achieved` counts ALGORITHMIC fp32 FLOP",
+                        "kernel": ("conv_h16_kernel + conv_h16_bal_kernel + resblock_pair_h16_kernel (fp32 contractions as 3 fp16 products of two block-scaled fp16 "
+                                   "pieces per operand on v_mfma_f32_32x32x16_f16, fp32 accumulation) + ln_mlp_split_kernel (6 bf16 products)") if ARITH == 16 else
+                                  ("conv_split_kernel + conv_split_bal_kernel + resblock_pair_split_kernel + ln_mlp_split_kernel (fp32 contractions as "
+                                   f"{SPLIT_PRODUCTS} bf16 products per element pair on v_mfma_f32_32x32x16_bf16, fp32 accumulation)"),
+                        "peak_note": f"2500 TFLOP/s dense 16-bit MFMA / {SPLIT_PRODUCTS} products per fp32 multiply-add; `achieved` counts ALGORITHMIC fp32 FLOP"
+                                     + (" (the feed-forward launches, 60 of them, execute 6 products: their share of `executed_tflops` is under-counted)" if ARITH == 16 else ""),
                         "executed_tflops": round(ach_split * SPLIT_PRODUCTS, 1), "peak_executed": PEAK_BF16_MFMA_TFLOPS,
-                        "sustained_note": "with real operand data the pure bf16 MFMA loop is power-limited to ~1800 TFLOP/s (clock 2.4 -> ~1.85 GHz, "
-                                          "tools/bf16_split_probe.hip), i.e. ~300 TFLOP/s of fp32-equivalent work",
+                        "sustained_note": "with real operand data the pure 16-bit MFMA loop is power-limited to ~1800 TFLOP/s (1.4 kW, clock 2.4 -> ~1.78 GHz: "
+                                          "tools/bf16_split_probe.hip, profiles/r03_clock_and_power_vocoder_loop.txt), i.e. ~600 TFLOP/s of fp32-equivalent work at 3 "
+                                          "products, ~300 at 6",
                         "launches_per_step": int(sp_n), "avg_launch_us": round(sp_ms * 1e3 / sp_n, 2), "alg_gflop_per_launch": round(sp_fl / sp_n / 1e9, 3),
                         "ms_per_step": round(sp_ms, 2),
                         "fp32_mfma_family": {"achieved": round(f32_fl / (f32_ms * 1e-3) / 1e12, 2) if f32_n else None, "peak": PEAK_FP32_MFMA_TFLOPS,
@@ -678,10 +689,12 @@ def main():
             "config": {"workload": f"config2: batch {B} x {T}-frame (5.99 s) utterances per GPU, {n_ode} Euler steps + HiFi-GAN V1, 22.05 kHz",
                        "global_batch": B * world, "frames": T, "ode_steps": n_ode, "parallelism": f"dp{world}",
                        "collective": "all_gather(waveforms)" if world > 1 else "none",
-                       "arithmetic": "f32 tensors and f32 accumulation throughout; EV_SPLIT=0 -> every product on the f32 MFMA" if DTYPE == "f32" else
-                                     "f32 tensors and f32 accumulation throughout; deep layers: operand = exact sum of 3 bf16 pieces, product = the 6 piece products of "
-                                     "weight <= 2 (drops < 2^-24 |ab|); dot products of length 1408 vs fp64: max rel err 3.4e-6 (f32 FMA chain: 3.1e-6), "
-                                     "profiles/r03_bf16_split_probe.txt; parity_* below are measured on this run's timed output",
+                       "arithmetic": "f32 tensors and f32 accumulation throughout; EV_SPLIT=0 -> every product on the f32 MFMA" if ARITH == 0 else
+                                     ("f32 tensors and f32 accumulation throughout; deep layers: operand = two fp16 pieces of the operand times a power-of-two block "
+                                      "scale (22-23 significand bits), product = h0g0 + h0g1 + h1g0; one conv layer vs fp64 (tools/arith_accuracy.py): rms 3.4e-7 of "
+                                      "the output scale against 5.4e-7 for the f32 MFMA; parity_* below are measured on this run's timed output") if ARITH == 16 else
+                                     "f32 tensors and f32 accumulation throughout; deep layers: operand = exact sum of 3 bf16 pieces, product = the piece products of "
+                                     "weight <= 2 (6) / <= 1 (3); profiles/r03_bf16_split_probe.txt; parity_* below are measured on this run's timed output",
                        "batch_pipeline": "off" if pipe is None else f"cfm(i+1) || hifigan(i) on two streams, {len(pipes)} pipeline(s) in flight",
                        "memory": "off" if pipe is None else f"{len(pipes)} engine pairs resident per GPU, each its own weights (0.3 GB: fp32 fragments + their bf16 piece planes) + workspace "
                                  f"({round(model.engine.workspace_bytes(B, T, 0) / 1e9 + voc.engine.workspace_bytes(B, 0, T) / 1e9, 1)} GB at this shape)"},

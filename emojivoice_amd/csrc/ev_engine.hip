@@ -33,6 +33,8 @@ struct Geom { int nrows, S, P, T; };  // flattened padded time axis of one resol
 // One convolution / linear layer packed for conv_gemm_kernel.
 struct ConvLayer {
     float* W = nullptr;       // [ntaps][Mpad][Kpad]
+    unsigned short* Wh = nullptr; float wh_scale = 1.f;   // the weights times wh_scale (a power of two: the largest lands in [8192, 16384)) as two fp16
+                                    // pieces in conv_h16_kernel's fragment order (Kpad % 16 == 0)
     unsigned short* Wx = nullptr;   // the same weights as three bf16 pieces in conv_split_kernel's fragment order (Kpad % 64 == 0 only)
     float* bias = nullptr;    // [Cout] (stacked / phase-replicated as needed) or null
     int2* taplist[3] = {nullptr, nullptr, nullptr};   // for BM = 128, 64, 32: [mtiles][EV_MAX_TAPS] {tap, row offset} (one shared row when dense)
@@ -149,9 +151,9 @@ struct ev_handle {
     int ncu = 0;                    // compute units of the device
     unsigned* sk_ctrl = nullptr;    // [0] epoch [1] arrivals [2] timed-out waits | flags from word 16 on
     float* sk_part = nullptr;
-    int split_terms = 6;            // bf16 products per fp32 product of the split builds (ev_set_arithmetic; EV_SPLIT presets it): 0 = fp32 MFMA
-                                    // everywhere, 6 = shipped, 3 = opt-in fast setting (conv_split_kernel and the fused pairs; not fp32-grade),
-                                    // 9 = accuracy A/B of conv_split_kernel
+    int split_terms = 16;           // arithmetic of the deep layers' products (ev_set_arithmetic; EV_SPLIT presets it): 16 = shipped: two block-scaled
+                                    // fp16 pieces per operand, three products (fp32-grade); 6 = three bf16 pieces, six products (fp32-grade, no
+                                    // range handling needed); 0 = fp32 MFMA everywhere; 3 = opt-in fast bf16 setting (not fp32-grade); 9 = A/B
     int last_cfg = -1;              // build the last launch_conv / launch_pair took (ev_dbg_last_cfg: tests assert that a shape ran on the build they mean)
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
     bool sk_spread = false;         // EV_SK_SPREAD=1: launches of fewer row tiles than CUs (small batches) spread their units over up to 2 x CUs workgroups
@@ -220,6 +222,29 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                             Wf[((((size_t)tap * MT32 + mt) * KG8 + kg) * 64 + lane) * 4 + e] = Wh[((size_t)tap * L.Mpad + row) * L.Kpad + k];
                         }
         if (dev_upload(h, Wf, &L.W)) return 1;
+    }
+    if (L.Kpad % 16 == 0) {   // conv_h16_kernel: (w * 2^k) = h0 + h1 to 2^-22, two fp16 pieces; order [tap][Mpad/32][Kpad/16][piece][lane][8]
+        float mx = 0.f;
+        for (float w : Wh) if (std::isfinite(w)) mx = std::max(mx, std::fabs(w));
+        int k = 0;
+        if (mx > 0.f) { int ex; std::frexp(mx, &ex); k = 14 - ex; }          // mx = m * 2^ex, m in [0.5, 1): mx * 2^(14 - ex) in [8192, 16384)
+        k = std::max(-100, std::min(100, k));
+        L.wh_scale = std::ldexp(1.0f, k);
+        const int MT32 = L.Mpad / 32, KG16 = L.Kpad / 16;
+        std::vector<unsigned short> Whp(Wh.size() * 2);
+        auto hbits = [](_Float16 v) { unsigned short u; memcpy(&u, &v, 2); return u; };
+        for (int tap = 0; tap < L.ntaps; ++tap)
+            for (int mt = 0; mt < MT32; ++mt)
+                for (int kg = 0; kg < KG16; ++kg)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 8; ++e) {
+                            const int row = mt * 32 + (lane & 31), kk = kg * 16 + 8 * (lane >> 5) + e;
+                            const float w = Wh[((size_t)tap * L.Mpad + row) * L.Kpad + kk] * L.wh_scale;
+                            const _Float16 h0 = (_Float16)w, h1 = (_Float16)(w - (float)h0);
+                            const size_t base = ((((size_t)tap * MT32 + mt) * KG16 + kg) * 2) * 512 + (size_t)lane * 8 + e;
+                            Whp[base] = hbits(h0); Whp[base + 512] = hbits(h1);
+                        }
+        if (dev_upload(h, Whp, &L.Wh)) return 1;
     }
     if (L.Kpad % 16 == 0) {   // conv_split_kernel / resblock_pair_split_kernel: w = w0 + w1 + w2 exactly, each piece the upper half of an fp32 word (bf16);
         // order [tap][Mpad/32][Kpad/16][piece][lane][8], lane = (row & 31) + 32 * half, element e <-> k = 16 kg + 8 half + e
@@ -487,6 +512,17 @@ void launch_split(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     else if (lean_acc(p)) { ensure_dyn_smem<conv_split_kernel<BM, BN, WM, WN, 3, TERMS>>(smem, lo.device); hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, 3, TERMS>), grid, dim3(256), smem, st, p); }
     else { ensure_dyn_smem<conv_split_kernel<BM, BN, WM, WN, 1, TERMS>>(smem, lo.device); hipLaunchKernelGGL((conv_split_kernel<BM, BN, WM, WN, 1, TERMS>), grid, dim3(256), smem, st, p); }
 }
+// conv_h16_kernel (fp16 two-piece, block-scaled): the lean epilogues only
+template <int BM, int BN, int WM, int WN>
+void launch_h16(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
+    const size_t xs = (size_t)(BN + EV_HALO) * EVH_RSB + 16;            // (the waves' maxima sit behind the largest tile)
+    constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4) * sizeof(float);
+    const size_t smem = xs > es ? xs : es;
+    const dim3 grid(p.mtiles * p.ntiles);
+    if (p.act == ACT_SNAKE) { ensure_dyn_smem<conv_h16_kernel<BM, BN, WM, WN, 2>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), smem, st, p); }
+    else if (lean_acc(p)) { ensure_dyn_smem<conv_h16_kernel<BM, BN, WM, WN, 3>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), smem, st, p); }
+    else { ensure_dyn_smem<conv_h16_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), smem, st, p); }
+}
 inline bool split_ok(const ConvLayer& L, const ConvParams& p0) {
     ConvParams p = p0;
     p.dbg &= ~4;                                        // (the no-epilogue ablation of tools/conv_bench.py exists in this build too)
@@ -579,6 +615,24 @@ int launch_split_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) 
     else { ensure_dyn_smem<conv_split_bal_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_split_bal_kernel<BM, BN, WM, WN, 1>), dim3(G), dim3(256), smem, h->stream, p); }
     return 0;
 }
+template <int BM, int BN, int WM, int WN>
+int launch_h16_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
+    if (ensure_sk(h)) return 1;
+    const int nchunks = p.Kpad / EVX_KC;
+    const long U = (long)p.mtiles * p.ntiles * nchunks;
+    const int G = wpc * h->ncu;
+    p.sk.ctrl = h->sk_ctrl; p.sk.flags = h->sk_ctrl + 16; p.sk.part = h->sk_part; p.sk.part_floats = EV_SK_PART_FLOATS;
+    p.sk.q = (int)(U / G); p.sk.r = (int)(U % G); p.sk.spin_limit = h->sk_spin;
+    const size_t xs = (size_t)(BN + ((lo.halo + 7) & ~7)) * EVH_RSB;
+    constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4) * sizeof(float);
+    size_t smem = xs > es ? xs : es;
+    p.sk.lds_word = (int)smem;
+    smem += 48;                                         // the wait word + the waves' pre-scan maxima
+    static_assert((size_t)BM * BN <= EV_SK_PART_FLOATS, "hand-off slot");
+    if (lean_acc(p)) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 3>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 3>), dim3(G), dim3(256), smem, h->stream, p); }
+    else { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 1>), dim3(G), dim3(256), smem, h->stream, p); }
+    return 0;
+}
 inline bool split_bal_ok(const ev_handle* h, const ConvLayer& L, const ConvParams& p, long nwg, int wpc) {
     static const bool off = getenv("EV_NO_CONV_BALANCE") != nullptr;
     return !off && h->sk_balance && h->ncu > 0 && split_ok(L, p) && p.act != ACT_SNAKE && !p.dbg && !p.stamps && !p.gn_part &&
@@ -609,7 +663,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     memset(&p, 0, sizeof p);
     h->gn_stats_tiles = 0;
     p.X = X; p.ldx = ldx; p.Cin = L.Cin; p.isplit_log2 = e.isplit_log2; p.isstride = e.isstride;
-    p.W = L.W; p.Wx = L.Wx; p.Mpad = L.Mpad; p.Kpad = L.Kpad; p.bias = L.bias;
+    p.W = L.W; p.Wx = L.Wx; p.Wh = L.Wh; p.wh_scale = L.wh_scale; p.Mpad = L.Mpad; p.Kpad = L.Kpad; p.bias = L.bias;
     p.Y = Y; p.ldy = ldy; p.Cout = L.Cout; p.osplit_log2 = e.osplit_log2; p.osstride = e.osstride; p.mmul = e.mmul;
     p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T;
     p.ntaps = L.ntaps; for (int i = 0; i < L.ntaps; ++i) p.off[i] = L.off[i];
@@ -696,13 +750,13 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         // the 64 x 128 tile below)
         const long nwg128 = (long)(L.Mpad / 128) * ((g.nrows + 127) / 128);
         if (split_terms > 0 && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && L.Cout % 128 == 0 && (!L.sparse_taps || (L.tile128_exact && L.kstack_mt == 0)) && nwg128 >= 2L * 2 * h->ncu && h->ncu > 0)
-            cfg = split_terms == 3 ? 43 : split_terms == 9 ? 49 : 40;
+            cfg = split_terms == 3 ? 43 : split_terms == 9 ? 49 : split_terms == 16 ? 46 : 40;
         // polyphase transposed convs (M tiles of 64 channels with different tap subsets) on deep grids: 64 x 128 tiles of the split build
-        else if ((split_terms == 6 || split_terms == 3) && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && L.Cout % 64 == 0 && L.kstack_mt == 0 && h->ncu > 0 &&
+        else if ((split_terms == 6 || split_terms == 3 || split_terms == 16) && (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && split_ok(L, p) && L.Cout % 64 == 0 && L.kstack_mt == 0 && h->ncu > 0 &&
                  (L.sparse_taps || L.Cout % 128 != 0) &&
                  (long)((L.Cout + 63) / 64) * ((g.nrows + 127) / 128) >= 2L * 3 * h->ncu) cfg = 41;
         // launches of a few rounds (the U-Net convs of a large-batch decode): the balanced persistent grid of the split build
-        else if (split_terms == 6 && (cfg == 1 || cfg == 5 || cfg == 6 || cfg == 0) && L.Cout == L.Mpad && split_bal_ok(h, L, p, nwg128, 2)) cfg = 60;
+        else if ((split_terms == 6 || split_terms == 16) && (cfg == 1 || cfg == 5 || cfg == 6 || cfg == 0) && L.Cout == L.Mpad && split_bal_ok(h, L, p, nwg128, 2)) cfg = 60;
     }
     {   // debugging / test override: EV_FORCE_CFG=<0..3> forces one tile configuration for every conv launch
         static const char* env = getenv("EV_FORCE_CFG");
@@ -732,15 +786,22 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
         static const char* senv = getenv("EV_STAGGER");
         if (senv && *senv) p.stagger_slots = atoi(senv) ? p.stagger_slots : 0;
     }
-    if ((cfg == 40 || cfg == 41 || cfg == 43 || cfg == 49 || cfg == 60) && !split_ok(L, p)) cfg = 0;
+    if ((cfg == 40 || cfg == 41 || cfg == 43 || cfg == 46 || cfg == 49 || cfg == 60) && !split_ok(L, p)) cfg = 0;
+    if (cfg == 46 && !L.Wh) cfg = 40;
+    if (cfg == 46) {   // 128 x 128 on the fp16 pipe, two block-scaled pieces, three products
+        p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
+        launch_h16<128, 128, 2, 2>(p, h->stream, lo);
+    } else
     if (cfg == 41) {   // 64 x 128 on the bf16 pipe (per-tile tap lists of the 64-channel tiling)
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
-        if (h->split_terms == 3) launch_split<64, 128, 2, 2, 3>(p, h->stream, lo); else launch_split<64, 128, 2, 2, 6>(p, h->stream, lo);
+        if (h->split_terms == 16 && L.Wh) { launch_h16<64, 128, 2, 2>(p, h->stream, lo); cfg = 47; }
+        else if (h->split_terms == 3) launch_split<64, 128, 2, 2, 3>(p, h->stream, lo); else launch_split<64, 128, 2, 2, 6>(p, h->stream, lo);
     } else
     if (cfg == 60) {   // 128 x 128 on the bf16 pipe, balanced persistent grid
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         static const int bal_wgs = getenv("EV_SPLIT_BAL_WGS") ? atoi(getenv("EV_SPLIT_BAL_WGS")) : 2;    // A/B: persistent workgroups per CU (1 or 2)
-        if (launch_split_bal<128, 128, 2, 2>(h, p, lo, bal_wgs == 1 ? 1 : 2)) return 1;
+        if (h->split_terms == 16 && L.Wh) { if (launch_h16_bal<128, 128, 2, 2>(h, p, lo, bal_wgs == 1 ? 1 : 2)) return 1; cfg = 66; }
+        else if (launch_split_bal<128, 128, 2, 2>(h, p, lo, bal_wgs == 1 ? 1 : 2)) return 1;
     } else
     if (cfg == 40 || cfg == 43 || cfg == 49) {   // 128 x 128 on the bf16 pipe
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
@@ -850,7 +911,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     p.ntaps = L2.ntaps; p.taplist = L2.taplist[0]; p.tl_stride = 0; p.nact_tab = nullptr;
     p.pro_lrelu = 1; p.pro_slope = 0.1f;
     p.scale = 1.f; p.R = X; p.ldr = C; p.accum = e.accum; p.div3 = e.div3; p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope;
-    pp.W1 = L1.W; pp.W1x = L1.Wx; p.Wx = L2.Wx; pp.b1 = L1.bias; pp.taplist1 = L1.taplist[0]; pp.ntaps1 = L1.ntaps;
+    pp.W1 = L1.W; pp.W1x = L1.Wx; p.Wx = L2.Wx; pp.W1h = L1.Wh; pp.w1h_scale = L1.wh_scale; p.Wh = L2.Wh; p.wh_scale = L2.wh_scale; pp.b1 = L1.bias; pp.taplist1 = L1.taplist[0]; pp.ntaps1 = L1.ntaps;
     pp.h1 = L1.halo_lo; pp.h2 = L2.halo_lo; pp.mid_slope = 0.1f;
     if ((double)g.nrows * C * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
     if (L1.sparse_taps || L2.sparse_taps || L1.Kpad != C || L2.Kpad != C || L1.Kpad != L2.Kpad || L1.Mpad != L2.Mpad || L1.halo_lo != L1.halo_hi ||
@@ -868,6 +929,19 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     const int lean = no_lean ? 0 : ((e.accum || e.div3 || e.act2_lrelu) ? 3 : 1);
     const int split_terms = h->split_terms;
     const bool split = split_terms > 0 && lean != 0 && L1.Wx && L2.Wx && !(e.force_cfg == 0);
+    const bool h16 = split && split_terms == 16 && L1.Wh && L2.Wh;
+    if (h16) {   // the fp16 build: two block-scaled fp16 planes per LDS row
+        const int NT = C == 32 ? 256 : C == 64 ? 128 : 64, RSB = 4 * C + 16;
+        if (C != 32 && C != 64 && C != 128) return fail(h, "launch_pair: C must be 32, 64 or 128");
+        pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
+        const size_t smem = std::max((size_t)(NT + EV_HALO) * RSB + 32, (size_t)4 * 32 * 36 * sizeof(float));
+        const dim3 grid(p.ntiles);
+#define EV_PAIR_H16(WM, WN) do { \
+            if (lean == 1) { ensure_dyn_smem<resblock_pair_h16_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_h16_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, pp); } \
+            else { ensure_dyn_smem<resblock_pair_h16_kernel<WM, WN, 3>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_h16_kernel<WM, WN, 3>), grid, dim3(256), smem, h->stream, pp); } } while (0)
+        if (C == 32) EV_PAIR_H16(1, 4); else if (C == 64) EV_PAIR_H16(2, 2); else EV_PAIR_H16(4, 1);
+#undef EV_PAIR_H16
+    } else
     if (split) {   // the bf16-split build: LDS rows hold all C channels as three bf16 planes
         const int NT = C == 32 ? 256 : C == 64 ? 128 : 64, RSB = 6 * C + 16;
         if (C != 32 && C != 64 && C != 128) return fail(h, "launch_pair: C must be 32, 64 or 128");
@@ -915,13 +989,13 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         return fail(h, "launch_pair: C must be 32, 64 or 128");
     }
     HIPCHK(h, hipGetLastError());
-    h->last_cfg = (split ? 140 : 100) + L2.ntaps;
+    h->last_cfg = (h16 ? 160 : split ? 140 : 100) + L2.ntaps;
     if (h->prof) {
         HIPCHK(h, hipEventRecord(e1, h->stream));
         const double valid_rows = (double)(g.nrows / g.S) * g.T;
         h->prof_flops += 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows;
         h->prof_launches += 1;
-        h->prof_recs.push_back({1, C, C, L1.ntaps, g.nrows, (split ? 140 : 100) + L2.ntaps, lean, 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows});
+        h->prof_recs.push_back({1, C, C, L1.ntaps, g.nrows, (h16 ? 160 : split ? 140 : 100) + L2.ntaps, lean, 2.0 * (L1.macs_per_row + L2.macs_per_row) * valid_rows});
     }
     return 0;
 }
@@ -993,7 +1067,7 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
         const int split_terms = h->split_terms;
         static const bool no_mlp_split = getenv("EV_NO_MLP_SPLIT") != nullptr;
         const int nt64 = (g.nrows + 63) / 64;
-        if (mode == 0 && split_terms == 6 && !no_mlp_split && L1.Wx && L2->Wx && h->sk_balance && h->ncu > 0 && h->ncu <= EV_SK_MAXWG && nt64 >= h->ncu) {
+        if (mode == 0 && (split_terms == 6 || split_terms == 16) && !no_mlp_split && L1.Wx && L2->Wx && h->sk_balance && h->ncu > 0 && h->ncu <= EV_SK_MAXWG && nt64 >= h->ncu) {
             if (ensure_sk(h)) return 1;
             const long U = (long)nt64 * nchunk;
             const int grid = h->ncu;
@@ -1733,7 +1807,7 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     { const char* fp = getenv("EV_FUSE_ATTN"); if (fp && *fp == '0') h->fuse_attn = false; }
     { const char* fp = getenv("EV_FUSE_MLP_MIN"); if (fp && *fp) h->fuse_mlp_min_tiles = atoi(fp); }
     { const char* fp = getenv("EV_MRF_STREAMS_MAX"); if (fp && *fp) h->mrf_max_frames = atoi(fp); }
-    { const char* sp = getenv("EV_SPLIT"); if (sp && *sp) { const int t = atoi(sp); h->split_terms = (t == 0 || t == 3 || t == 6 || t == 9) ? t : 6; } }
+    { const char* sp = getenv("EV_SPLIT"); if (sp && *sp) { const int t = atoi(sp); h->split_terms = (t == 0 || t == 3 || t == 6 || t == 9 || t == 16) ? t : 16; } }
     { const char* fp = getenv("EV_NO_SK_BALANCE"); if (fp && *fp && *fp != '0') h->sk_balance = false; }
     { const char* fp = getenv("EV_SK_SPIN"); if (fp && *fp) h->sk_spin = atoi(fp); }
     { const char* fp = getenv("EV_SK_WGS"); if (fp && *fp) h->sk_wgs = std::min(3, std::max(1, atoi(fp))); }
@@ -2396,7 +2470,8 @@ int ev_dbg_last_cfg(ev_handle* h) { return h ? h->last_cfg : -1; }
 // 0 = every layer on the fp32 MFMA.  Takes effect with the next call on this handle; results of the two settings agree to fp32 rounding.
 int ev_set_arithmetic(ev_handle* h, int bf16_products) {
     if (!h) return 1;
-    if (bf16_products != 0 && bf16_products != 3 && bf16_products != 6 && bf16_products != 9) return fail(h, "ev_set_arithmetic: 0, 3, 6 or 9 products, got %d", bf16_products);
+    if (bf16_products != 0 && bf16_products != 3 && bf16_products != 6 && bf16_products != 9 && bf16_products != 16)
+        return fail(h, "ev_set_arithmetic: 0, 3, 6, 9 or 16, got %d", bf16_products);
     h->split_terms = bf16_products;
     return 0;
 }
@@ -2412,7 +2487,7 @@ int ev_profile_read_split(ev_handle* h, double* ms_out, double* flops_out, int64
     if (h->prof_recs.size() * 2 == h->ev_used)
         for (size_t i = 0; i < h->prof_recs.size(); ++i) {
             const auto& r = h->prof_recs[i];
-            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && r.cfg == 120);
+            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 46 || r.cfg == 47 || r.cfg == 66 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && r.cfg == 120);
             if (!split) continue;
             float t = 0;
             HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));

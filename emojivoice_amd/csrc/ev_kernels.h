@@ -52,6 +52,7 @@ struct ConvParams {
     const float* X; int ldx; int Cin;
     int isplit_log2, isstride;              // input column ci lives at (ci >> isplit_log2)*isstride + (ci & (2^isplit_log2 - 1))
     const float* W; int Mpad; int Kpad;     // fragment order [ntaps][Mpad/32][Kpad/8][64 lanes][4]
+    const void* Wh; float wh_scale;         // conv_h16_kernel: the weights times wh_scale (a power of two) as two fp16 pieces, [ntaps][Mpad/32][Kpad/16][2][64 lanes][8]
     const void* Wx;                         // conv_split_kernel: the same weights as three bf16 pieces, [ntaps][Mpad/32][Kpad/16][3][64 lanes][8] (null: not packed)
     const float* bias;                      // [Cout] or null
     float* Y; int ldy; int Cout;
@@ -1236,6 +1237,236 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bal_kernel(const ConvParams 
 }
 
 // ---------------------------------------------------------------------------
+// conv_h16_kernel: conv_split_kernel with fp16 pieces.  An fp16 value carries 11 significand bits, so TWO pieces (x = h0 + h1, h0 = the
+// nearest fp16, h1 = the nearest fp16 of the rest) represent an fp32 operand to 2^-22..2^-23, and the three products h0 g0 + h0 g1 + h1 g0
+// (what is left out is below 2^-22 |a b|) give dot products whose error against fp64 is that of the fp32 FMA chain — measured (in-run probe,
+// length 1408): max 2.4e-6 / rms 4.3e-7 against 3.1e-6 / 6.9e-7 — for HALF the MFMAs of the bf16 form.  What fp16 lacks is RANGE (6e-8 ..
+// 65504), so both operands are block-scaled by exact powers of two:
+//   weights:     one scale per layer, chosen by the loader so that the largest weight lands in [8192, 16384)
+//   activations: one scale per workgroup tile, from a pre-scan of the rows it is about to stage (max |x| after the prologue): the largest
+//                staged value lands in [8192, 16384); values many octaves below the tile's maximum lose relative precision, which is
+//                irrelevant in a sum dominated by the large ones; an all-zero tile takes scale 1
+// The accumulators run in scaled units (bias preloaded times both scales) and are brought back by one exact multiplication per
+// register before the epilogue.  LDS row = two fp16 planes of the 64-channel chunk + 16 bytes (272 = 17 x 16).
+// ---------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#define EVH_RSB (2 * EVX_KC * 2 + 16)
+// two fp16 pieces of four fp32 values (already scaled), packed in channel order (8 bytes per piece)
+__device__ __forceinline__ void evh_split4(const f32x4 v, uint2& q0, uint2& q1) {
+    _Float16 h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { h[e] = (_Float16)v[e]; l[e] = (_Float16)(v[e] - (float)h[e]); }
+    const f16x2 a = {h[0], h[1]}, b = {h[2], h[3]}, c = {l[0], l[1]}, d = {l[2], l[3]};
+    q0.x = __builtin_bit_cast(unsigned, a); q0.y = __builtin_bit_cast(unsigned, b);
+    q1.x = __builtin_bit_cast(unsigned, c); q1.y = __builtin_bit_cast(unsigned, d);
+}
+// power of two s with max * s in [8192, 16384)  (max = 0 or not finite: 1)
+__device__ __forceinline__ float evh_scale_for(float mx) {
+    const int ex = (int)((__float_as_uint(mx) >> 23) & 255u);          // biased exponent of max
+    if (ex == 0 || ex == 255) return 1.f;
+    return __uint_as_float((unsigned)(127 + 13 - (ex - 127)) << 23);   // 2^(13 - floor(log2 max))
+}
+template <int TM, int TN>
+__device__ __forceinline__ void evh_mma(f32x16 (&acc)[TM][TN], const f32x4 (&a)[2][TM], const f32x4 (&b)[2][TN]) {
+    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[PA[t]][i]), __builtin_bit_cast(f16x8, b[PB[t]][j]), acc[i][j], 0, 0, 0);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN>
+__global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
+    constexpr int TM = BM / WAVES_M / 32;
+    constexpr int TN = BN / WAVES_N / 32;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;                            // [(BN + halo)][EVH_RSB bytes]
+    float* red = smem + ((BN + EV_HALO) * EVH_RSB) / 4;  // 4 floats behind the tile: the waves' maxima
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+
+    const int nwg = p.mtiles * p.ntiles;
+    const int work = ev_xcd_remap(blockIdx.x, nwg);
+    const int mt = work % p.mtiles;
+    const int nt = work / p.mtiles;
+    const int m0 = mt * BM;
+    const int n0 = nt * BN;
+    {   // tiles that contain no storable row (pure padding) do nothing
+        const int t_first = (n0 % p.S) - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - (n0 % p.S) + p.P;
+        if (dist >= BN || n0 + dist >= p.nrows) return;
+    }
+    const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
+    const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
+
+    const int xrows = BN + p.halo_lo + p.halo_hi;
+    constexpr int TPR = EVX_KC / 4, RPS = 256 / TPR;   // staging: 16 threads per row, 16 rows per pass
+    const int srow = tid / TPR;
+    const int sc4 = (tid % TPR) * 4;
+    const int nchunks = p.Kpad / EVX_KC;
+    constexpr int XPASS = (BN + EV_HALO) / RPS;
+    constexpr int XG = XPASS % 6 == 0 ? 6 : 4;
+    static_assert(XPASS % XG == 0, "staging batches");
+    const int mt32 = (m0 + wm * (TM * 32)) >> 5;
+    const int KG16 = p.Kpad >> 4;
+    const __amdgpu_buffer_rsrc_t rW = ev_rsrc(p.Wh), rX = ev_rsrc(p.X);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned wbase = (unsigned)(mt32 * KG16) * 2048u;
+    // (a tap's fp16 plane — (Mpad/32) (Kpad/16) x 2 KiB — is as large as its fp32 plane: the tap list's byte offsets apply as they are)
+    auto a_off = [&](int tap_bytes, int kg16) -> unsigned { return (unsigned)tap_bytes + wbase + (unsigned)kg16 * 2048u; };
+    f32x4 A0[2][TM], A1[2][TM], A2[2][TM], A3[2][TM], B0[2][TN], B1[2][TN];
+    auto ldAp = [&](f32x4 (&dst)[2][TM], unsigned aoff) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) dst[pc][i] = ev_bload4(rW, wlane, aoff + (unsigned)(i * KG16 * 2048 + pc * 1024));
+    };
+    auto ldB = [&](f32x4 (&dst)[2][TN], const char* brow, int slab) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dst[pc][j] = *(const f32x4*)(brow + j * 32 * EVH_RSB + pc * (EVX_KC * 2) + slab * 32);
+    };
+    const char* bbase = Xb + (wn * (TN * 32) + li + p.halo_lo) * EVH_RSB + 16 * lh;
+    const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
+    const int2 tv_first = ev_tap_at(tlv, 0);
+    if (nact > 0) {
+        const unsigned a0 = a_off(tv_first.x, 0);
+        ldAp(A0, a0); ldAp(A1, a0 + 2048u); ldAp(A2, a0 + 4096u); ldAp(A3, a0 + 6144u);
+    }
+    unsigned xoff[XPASS];
+#pragma unroll
+    for (int q = 0; q < XPASS; ++q) {
+        const int gr = n0 - p.halo_lo + q * RPS + srow;
+        xoff[q] = ((q * RPS < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
+    }
+    // ---- pre-scan: max |x| (after the prologue: |lrelu(x)| <= |x|, so the raw maximum bounds it) over everything this tile stages
+    float xs;
+    {
+        float mx = 0.f;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+#pragma unroll
+            for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                if (q0 * RPS >= xrows) continue;
+                f32x4 xg[XG];
+#pragma unroll
+                for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff[q0 + q], soff);
+#pragma unroll
+                for (int q = 0; q < XG; ++q) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xg[q][0]), fabsf(xg[q][1]))), fmaxf(fabsf(xg[q][2]), fabsf(xg[q][3])));
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) red[wave] = mx;
+        ev_lds_barrier();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        xs = evh_scale_for(mx);
+    }
+    const float acc_in = p.wh_scale * xs;              // bias in accumulator units
+    const float acc_out = 1.0f / acc_in;               // (both powers of two: exact)
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        f32x4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bq[g] = z;
+            const int c0 = m0 + wm * (TM * 32) + a * 32 + 8 * g + 4 * lh;
+            if (p.bias && c0 < p.Cout) bq[g] = *(const f32x4*)(p.bias + c0) * acc_in;
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = bq[r >> 2][r & 3];
+    }
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __builtin_amdgcn_s_setprio(3);
+        ev_lds_barrier();                               // the previous chunk's MFMAs are done with the tile
+        {
+            const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+#pragma unroll
+            for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                if (q0 * RPS >= xrows) continue;
+                f32x4 xg[XG];
+#pragma unroll
+                for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff[q0 + q], soff);      // (passes beyond the tile re-read row 0)
+#pragma unroll
+                for (int q = 0; q < XG; ++q) {
+                    const int r = (q0 + q) * RPS + srow;
+                    f32x4 v = xg[q];
+                    if (p.pro_lrelu) {
+                        v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                        v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                    }
+                    uint2 q0v, q1v;
+                    evh_split4(v * xs, q0v, q1v);
+                    if (r < xrows) {
+                        char* dst = Xb + r * EVH_RSB + sc4 * 2;
+                        *(uint2*)(dst) = q0v; *(uint2*)(dst + EVX_KC * 2) = q1v;
+                    }
+                }
+            }
+        }
+        ev_lds_barrier();
+        __builtin_amdgcn_s_setprio(0);
+        const char* brow = bbase + tv_first.y * EVH_RSB;
+        ldB(B0, brow, 0);
+        for (int ti = 0; ti < nact; ++ti) {
+            const bool last_tap = (ti + 1 == nact);
+            const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
+            const char* nbrow = bbase + ntv.y * EVH_RSB;
+            const bool have_next = !(last_tap && ch + 1 == nchunks);
+            const unsigned nap = have_next ? a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4) : a_off(tv_first.x, 0);   // unconditional loads
+            ldB(B1, brow, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            evh_mma<TM, TN>(acc, A0, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A0, nap);
+            ldB(B0, brow, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            evh_mma<TM, TN>(acc, A1, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A1, nap + 2048u);
+            ldB(B1, brow, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            evh_mma<TM, TN>(acc, A2, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A2, nap + 4096u);
+            ldB(B0, nbrow, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            evh_mma<TM, TN>(acc, A3, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(A3, nap + 6144u);
+            brow = nbrow;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] *= acc_out;
+    __builtin_amdgcn_s_setprio(3);
+    conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+}
+
+// ---------------------------------------------------------------------------
 // conv_split_bal_kernel: the balanced persistent grid of conv_gemm_bal_kernel with the K loop of conv_split_kernel (bf16 pipe, six
 // exact products per element pair).  A unit = (tile, 64-channel chunk); hand-off, tags, bounded waits and the recompute fallback
 // are those of SkCtl.  Layers whose M tiles carry different tap counts (a 3-tap conv stacked over a 1x1 conv) take it too, with
@@ -1400,6 +1631,256 @@ __global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams
                     brow = nbrow;
                 }
             }
+            auto acc_io = [&](unsigned base, int mode) {    // mode 0: store (write-through), 1: add from memory
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned off = base + pelem + (unsigned)((a * TN + b) * 4 + q) * 1024u;
+                            if (mode == 0) {
+                                const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                                ev_bstore4_sc1(rPart, off, v);
+                            } else {
+                                const f32x4 v = ev_bload4_sc1(rPart, off);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc[a][b][4 * q + e] += v[e];
+                            }
+                        }
+            };
+            if (spilled) { acc_io((unsigned)g * pslot + pslot / 2, 1); spilled = false; }
+            if (c0 != 0) {                                 // not the owner: hand the partial tile over (flag raised at the next segment)
+                acc_io((unsigned)g * pslot, 0);
+                pend_pub = true;
+                break;
+            }
+            bool again = false;
+            while (c1 < nchunks) {                         // owner: add the contributors' partial tiles in ascending workgroup order
+                int n = 0;
+                while (n < 64 && gi + n < (int)gridDim.x && sk_start(p.sk, gi + n) < tile_end) ++n;
+                if (n == 0) break;
+                const int ready = sk_wait_many(p.sk, gi, n, tag, tid, skw);
+                for (int k = 0; k < ready; ++k) acc_io((unsigned)(gi + k) * pslot, 1);
+                gi += ready;
+                if (ready < n) {                           // gi is not there in time: spill the running sum, compute its share here
+                    const int sgi = sk_start(p.sk, gi);
+                    int egi = sk_start(p.sk, gi + 1);
+                    egi = egi < tile_end ? egi : tile_end;
+                    acc_io((unsigned)g * pslot + pslot / 2, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    cA = sgi - t * nchunks; cB = egi - t * nchunks;
+                    spilled = true; again = true;
+                    ++gi;
+                    break;
+                }
+            }
+            if (again) continue;
+            __builtin_amdgcn_s_setprio(3);
+            conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+            __builtin_amdgcn_s_setprio(0);
+            break;
+        }
+    }
+    if (pend_pub) sk_publish(p.sk, g, tag, tid);
+    sk_arrive(p.sk, tag, tid);
+}
+
+// ---------------------------------------------------------------------------
+// conv_h16_bal_kernel: conv_split_bal_kernel with the fp16 form of conv_h16_kernel.  Every pass over a chunk range pre-scans what it will
+// stage for its activation scale and brings its accumulators back to true units before they are handed over, spilled or stored, so
+// workgroups that share a tile may run different scales.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN>
+__global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p) {
+    constexpr int TM = BM / WAVES_M / 32;
+    constexpr int TN = BN / WAVES_N / 32;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1 && LEAN != 0, "balanced build: 4 waves, lean epilogue");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nchunks = p.Kpad / EVX_KC;
+    const int g = blockIdx.x;
+    const unsigned tag = sk_tag(p.sk);
+    int u = sk_start(p.sk, g);
+    const int ue = sk_start(p.sk, g + 1);
+    const __amdgpu_buffer_rsrc_t rPart = ev_rsrc(p.sk.part), rW = ev_rsrc(p.Wh), rX = ev_rsrc(p.X);
+    const unsigned pslot = (unsigned)p.sk.part_floats * 8u;
+    constexpr int PN = TM * TN * 4;
+    const unsigned pelem = (unsigned)(wave * PN) * 1024u + (unsigned)lane * 16u;
+    int* skw = (int*)((char*)smem + p.sk.lds_word);
+    float* hred = (float*)((char*)smem + p.sk.lds_word + 16);                 // the waves' maxima of a pass's pre-scan
+    bool pend_pub = false;
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int KG16 = p.Kpad >> 4;
+    constexpr int TPR = EVX_KC / 4, RPS = 256 / TPR;
+    const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
+    constexpr int XPASS = (BN + EV_HALO) / RPS;
+    constexpr int XG = 4;
+    static_assert(XPASS % XG == 0, "staging batches");
+    const int xrows = BN + p.halo_lo + p.halo_hi;
+
+    while (u < ue) {
+        const int t = u / nchunks, c0 = u - t * nchunks;
+        const int c1 = (ue - u < nchunks - c0) ? c0 + (ue - u) : nchunks;
+        u += c1 - c0;
+        const int mt = t % p.mtiles, nt = t / p.mtiles;
+        const int m0 = mt * BM, n0 = nt * BN;
+        {   // tiles that contain no storable row (pure padding) do nothing — owner and contributors agree, the test only reads t
+            int t_first = (n0 % p.S) - p.P;
+            int dist;
+            if (t_first >= 0 && t_first < p.T) dist = 0;
+            else if (t_first < 0) dist = -t_first;
+            else dist = p.S - (n0 % p.S) + p.P;
+            if (dist >= BN || n0 + dist >= p.nrows) continue;
+        }
+        if (pend_pub) { sk_publish(p.sk, g, tag, tid); pend_pub = false; }
+        const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
+        const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
+        const int mt32 = (m0 + wm * (TM * 32)) >> 5;
+        const unsigned wbase = (unsigned)(mt32 * KG16) * 2048u;
+        auto a_off = [&](int tap_bytes, int kg16) -> unsigned { return (unsigned)tap_bytes + wbase + (unsigned)kg16 * 2048u; };
+        f32x4 A0[2][TM], A1[2][TM], A2[2][TM], A3[2][TM], B0[2][TN], B1[2][TN];
+        auto ldAp = [&](f32x4 (&dst)[2][TM], unsigned aoff) {
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) dst[pc][i] = ev_bload4(rW, wlane, aoff + (unsigned)(i * KG16 * 2048 + pc * 1024));
+        };
+        auto ldB = [&](f32x4 (&dst)[2][TN], const char* brow, int slab) {
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) dst[pc][j] = *(const f32x4*)(brow + j * 32 * EVH_RSB + pc * (EVX_KC * 2) + slab * 32);
+        };
+        const char* bbase = Xb + (wn * (TN * 32) + li + p.halo_lo) * EVH_RSB + 16 * lh;
+        const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
+        const int2 tv_first = ev_tap_at(tlv, 0);
+        const int gr0 = n0 - p.halo_lo + srow;             // first staging row of this thread (rows outside the tensor / the tile read pad row 0)
+        auto xoff = [&](int q) -> unsigned {
+            const int gr = gr0 + q * RPS;
+            return ((q * RPS < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
+        };
+        int cA = c0, cB = c1;
+        bool spilled = false;
+        int gi = g + 1;
+        const int tile_end = (t + 1) * nchunks;
+        for (;;) {
+            // pre-scan of the chunks this pass stages: their maximum sets the pass's activation scale (conv_h16_kernel)
+            float xs;
+            {
+                float mx = 0.f;
+                for (int ch = cA; ch < cB; ++ch) {
+                    const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+#pragma unroll
+                    for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                        if (q0 * RPS >= xrows) continue;
+                        f32x4 xg[XG];
+#pragma unroll
+                        for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff(q0 + q), soff);
+#pragma unroll
+                        for (int q = 0; q < XG; ++q) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xg[q][0]), fabsf(xg[q][1]))), fmaxf(fabsf(xg[q][2]), fabsf(xg[q][3])));
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                ev_lds_barrier();                          // (the previous pass / segment is done with LDS)
+                if (lane == 0) hred[wave] = mx;
+                ev_lds_barrier();
+                xs = evh_scale_for(fmaxf(fmaxf(hred[0], hred[1]), fmaxf(hred[2], hred[3])));
+            }
+            const float acc_in = p.wh_scale * xs, acc_out = 1.0f / acc_in;
+            f32x16 acc[TM][TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                f32x4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    bq[q] = z;
+                    const int cc = m0 + wm * (TM * 32) + a * 32 + 8 * q + 4 * lh;   // bias preloaded (lean epilogue), by the owner's first pass only
+                    if (p.bias && cA == 0 && cc < p.Cout) bq[q] = *(const f32x4*)(p.bias + cc) * acc_in;
+                }
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] = bq[r >> 2][r & 3];
+            }
+            if (nact > 0) {
+                const unsigned a0 = a_off(tv_first.x, cA * 4);
+                ldAp(A0, a0); ldAp(A1, a0 + 2048u); ldAp(A2, a0 + 4096u); ldAp(A3, a0 + 6144u);
+            }
+            for (int ch = cA; ch < cB; ++ch) {
+                __builtin_amdgcn_s_setprio(3);
+                ev_lds_barrier();                          // the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
+                {
+                    const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+#pragma unroll
+                    for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                        if (q0 * RPS >= xrows) continue;
+                        f32x4 xg[XG];
+#pragma unroll
+                        for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff(q0 + q), soff);
+#pragma unroll
+                        for (int q = 0; q < XG; ++q) {
+                            const int r = (q0 + q) * RPS + srow;
+                            f32x4 v = xg[q];
+                            if (p.pro_lrelu) {
+                                v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                                v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                            }
+                            uint2 q0v, q1v;
+                            evh_split4(v * xs, q0v, q1v);
+                            if (r < xrows) {
+                                char* dst = Xb + r * EVH_RSB + sc4 * 2;
+                                *(uint2*)(dst) = q0v; *(uint2*)(dst + EVX_KC * 2) = q1v;
+                            }
+                        }
+                    }
+                }
+                ev_lds_barrier();
+                __builtin_amdgcn_s_setprio(0);
+                const char* brow = bbase + tv_first.y * EVH_RSB;
+                ldB(B0, brow, 0);
+                for (int ti = 0; ti < nact; ++ti) {
+                    const bool last_tap = (ti + 1 == nact);
+                    const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
+                    const char* nbrow = bbase + ntv.y * EVH_RSB;
+                    const bool have_next = !(last_tap && ch + 1 == cB);
+                    const unsigned nap = have_next ? a_off(ntv.x, last_tap ? ch * 4 + 4 : ch * 4) : a_off(tv_first.x, cA * 4);
+                    ldB(B1, brow, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    evh_mma<TM, TN>(acc, A0, B0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A0, nap);
+                    ldB(B0, brow, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    evh_mma<TM, TN>(acc, A1, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A1, nap + 2048u);
+                    ldB(B1, brow, 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    evh_mma<TM, TN>(acc, A2, B0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A2, nap + 4096u);
+                    ldB(B0, nbrow, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    evh_mma<TM, TN>(acc, A3, B1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ldAp(A3, nap + 6144u);
+                    brow = nbrow;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][b][r] *= acc_out;      // back to true units: partial tiles are handed over in them
             auto acc_io = [&](unsigned base, int mode) {    // mode 0: store (write-through), 1: add from memory
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
@@ -1885,6 +2366,7 @@ __global__ __launch_bounds__(512, 4) void conv_sk32_kernel(const ConvParams pk) 
 struct PairParams {
     ConvParams c2;                 // c2 + epilogue view: X = x (input), W/bias/taplist = c2's, R = x, Y = output, flags
     const float* W1; const float* b1; const int2* taplist1; int ntaps1;
+    const void* W1h; float w1h_scale;   // resblock_pair_h16_kernel: c1's weights times w1h_scale as two fp16 pieces (c2's: c2.Wh, c2.wh_scale)
     const void* W1x;               // resblock_pair_split_kernel: c1's weights as three bf16 pieces (c2's: c2.Wx)
     int h1, h2;                    // halos of c1 (dilated) and c2
     float mid_slope;               // leaky-relu slope between the convs
@@ -2241,6 +2723,209 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_split_kernel(const PairP
     // ---------------- phase 2: c2 over the LDS-resident y1 (tap offset t reads rows r + h2 + t)
     kloop(rW2, tlv2, ng2, Xb + (wn * (TN * 32) + li + pp.h2) * RSB + 16 * lh);
 
+    conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
+}
+
+// ---------------------------------------------------------------------------
+// resblock_pair_h16_kernel: the fused ResBlock pair with fp16 pieces (conv_h16_kernel: two block-scaled fp16 pieces per operand, three
+// products per fp32 product).  Scales, all exact powers of two: the layers' weight scales from the loader; sx from the maximum of the X
+// tile, which is loaded into registers ONCE (maximum, then leaky-relu, scaling, split, LDS); sy from the maximum of the intermediate
+// lrelu(c1 + b1) over the workgroup's tile, exchanged through LDS at the barrier the hand-over has anyway.  LDS row = two fp16 planes of
+// all C channels + 16 bytes (144 / 272 / 528 = 9, 17, 33 x 16).
+// ---------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int LEAN>
+__global__ __launch_bounds__(256, 2) void resblock_pair_h16_kernel(const PairParams pp) {
+    constexpr int TM = 1, TN = 2;
+    constexpr int C = 32 * WAVES_M;
+    constexpr int NT = WAVES_N * TN * 32;
+    constexpr int RSB = 4 * C + 16;                     // LDS row stride in bytes
+    constexpr int NS = C / 16, H = NS / 2;              // slabs per tap; two-slab groups per tap
+    constexpr int TPR = C / 4, RPS = 256 / TPR;         // staging: threads per row, rows per pass
+    constexpr int XPASS = (NT + EV_HALO) / RPS;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    const ConvParams& p = pp.c2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;                             // phase 1: [NT + 2 h1][RSB];  phase 2 (aliased): y1 [NT + 2 h2][RSB]
+    float* red = smem + ((NT + EV_HALO) * RSB) / 4;     // 8 floats behind the tiles: the waves' maxima (x: 0..3, y1: 4..7)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+    const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
+
+    const int nt = ev_xcd_remap(blockIdx.x, p.ntiles);
+    const int n0 = nt * pp.out_rows;
+    const int g0 = n0 - pp.h2;
+    {   // tiles whose output window holds no storable row do nothing
+        const int s0 = n0 % p.S, t_first = s0 - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - s0 + p.P;
+        if (dist >= pp.out_rows || n0 + dist >= p.nrows) return;
+    }
+    const int KG16 = p.Kpad >> 4;
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned wbase = (unsigned)(wm * KG16) * 2048u;
+    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(p.X);
+    f32x16 acc[TM][TN];
+    f32x4 A0[2][TM], A1[2][TM], A2[2][TM], A3[2][TM], B0[2][TN], B1[2][TN];
+
+    auto ldAp = [&](const __amdgpu_buffer_rsrc_t& rW, f32x4 (&dst)[2][TM], unsigned aoff) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) dst[pc][0] = ev_bload4(rW, wlane, aoff + (unsigned)(pc * 1024));
+    };
+    auto ldB = [&](f32x4 (&dst)[2][TN], const char* brow, int slab) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dst[pc][j] = *(const f32x4*)(brow + j * 32 * RSB + pc * (2 * C) + slab * 32);
+    };
+    // group g of a phase = slabs 2 (g % H), 2 (g % H) + 1 of tap g / H (a tap's fp16 plane is as large as its fp32 plane: the tap list's
+    // byte offsets apply as they are)
+    auto g_off = [&](int2 tlv, int g, int ngroups) -> unsigned {
+        const int gg = g < ngroups ? g : 0;             // (beyond the phase: a harmless re-read)
+        return (unsigned)__builtin_amdgcn_readlane(tlv.x, gg / H) + wbase + (unsigned)(2 * (gg % H)) * 2048u;
+    };
+    auto g_row = [&](int2 tlv, int g, int ngroups) -> int {
+        const int gg = g < ngroups ? g : 0;
+        return __builtin_amdgcn_readlane(tlv.y, gg / H);
+    };
+    auto acc_init = [&](const float* binit, float unit) {   // bias in accumulator units
+        f32x4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *(const f32x4*)(binit + wm * 32 + 8 * g + 4 * lh) * unit;
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][b][r] = bq[r >> 2][r & 3];
+    };
+    auto ring_fill = [&](const __amdgpu_buffer_rsrc_t& rW, int2 tlv, int ngroups) {
+        const unsigned o0 = g_off(tlv, 0, ngroups), o1 = g_off(tlv, 1, ngroups);
+        ldAp(rW, A0, o0); ldAp(rW, A1, o0 + 2048u); ldAp(rW, A2, o1); ldAp(rW, A3, o1 + 2048u);
+    };
+    auto kloop = [&](const __amdgpu_buffer_rsrc_t& rW, int2 tlv, int ngroups, const char* bbase) {
+        auto group = [&](f32x4 (&Aa)[2][TM], f32x4 (&Ab)[2][TM], int g) {
+            const char* brow = bbase + g_row(tlv, g, ngroups) * RSB;
+            const char* nbrow = bbase + g_row(tlv, g + 1, ngroups) * RSB;
+            const int s0 = 2 * (g % H), ns0 = 2 * ((g + 1) % H);
+            const unsigned nap = g_off(tlv, g + 2, ngroups);
+            ldB(B1, brow, s0 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            evh_mma<TM, TN>(acc, Aa, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(rW, Aa, nap);
+            ldB(B0, nbrow, ns0);
+            __builtin_amdgcn_sched_barrier(0);
+            evh_mma<TM, TN>(acc, Ab, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(rW, Ab, nap + 2048u);
+        };
+        ldB(B0, bbase + g_row(tlv, 0, ngroups) * RSB, 0);
+        int g = 0;
+        for (; g + 1 < ngroups; g += 2) { group(A0, A1, g); group(A2, A3, g + 1); }
+        if (g < ngroups) group(A0, A1, g);
+    };
+    auto wg_max = [&](float mx, int slot) -> float {        // workgroup maximum through LDS (one barrier)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) red[slot + wave] = mx;
+        ev_lds_barrier();
+        return fmaxf(fmaxf(red[slot], red[slot + 1]), fmaxf(red[slot + 2], red[slot + 3]));
+    };
+
+    // ---------------- phase 1: c1 over lrelu(x); X tile rows [g0 - h1, g0 + NT + h1), all channels, loaded once
+    const __amdgpu_buffer_rsrc_t rW1 = ev_rsrc(pp.W1h), rW2 = ev_rsrc(p.Wh);
+    const int ng1 = pp.ntaps1 * H, ng2 = p.ntaps * H;
+    const int2 tlv1 = (lane < pp.ntaps1) ? pp.taplist1[lane] : make_int2(0, 0);
+    const int2 tlv2 = (lane < p.ntaps) ? p.taplist[lane] : make_int2(0, 0);
+    ring_fill(rW1, tlv1, ng1);
+    float sx;
+    {
+        const int xrows = NT + 2 * pp.h1;
+        f32x4 xg[XPASS];
+        float mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) {
+            const int r = q * RPS + srow;
+            const int gr = g0 - pp.h1 + r;
+            xg[q] = ev_bload4(rX, ((r < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u, 0);   // (row 0 is a zero pad row)
+        }
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xg[q][0]), fabsf(xg[q][1]))), fmaxf(fabsf(xg[q][2]), fabsf(xg[q][3])));
+        sx = evh_scale_for(wg_max(mx, 0));              // (|lrelu(x)| <= |x|)
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) {
+            const int r = q * RPS + srow;
+            f32x4 v = xg[q];
+            v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+            v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+            uint2 q0v, q1v;
+            evh_split4(v * sx, q0v, q1v);
+            if (r < xrows) {
+                char* dst = Xb + r * RSB + sc4 * 2;
+                *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v;
+            }
+        }
+    }
+    const float u1 = pp.w1h_scale * sx;
+    acc_init(pp.b1, u1);
+    ev_lds_barrier();
+    kloop(rW1, tlv1, ng1, Xb + (wn * (TN * 32) + li + pp.h1) * RSB + 16 * lh);
+    ring_fill(rW2, tlv2, ng2);                           // c2's first fragments fly under the hand-over below
+
+    // ---------------- y1 = lrelu(c1 + b1), zero outside the utterance; its maximum over the workgroup -> sy; split into LDS rows r + h2
+    float sy;
+    {
+        const float inv1 = 1.0f / u1;
+        float my = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * (TN * 32) + j * 32 + li;
+            const int n = g0 + r;
+            const int t = (n >= 0 && n < p.nrows) ? (n % p.S) - p.P : -1;
+            const float inside = (t >= 0 && t < p.T) ? inv1 : 0.f;
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) {
+                const float v = ev_lrelu(acc[0][j][r16] * inside, pp.mid_slope);    // (back to true units; 0 outside the utterance)
+                acc[0][j][r16] = v;
+                my = fmaxf(my, fabsf(v));
+            }
+        }
+        sy = evh_scale_for(wg_max(my, 4));              // (the barrier inside: every wave is done reading the X tile)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * (TN * 32) + j * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = {acc[0][j][4 * g] * sy, acc[0][j][4 * g + 1] * sy, acc[0][j][4 * g + 2] * sy, acc[0][j][4 * g + 3] * sy};
+                uint2 q0v, q1v;
+                evh_split4(v, q0v, q1v);
+                char* dst = Xb + (r + pp.h2) * RSB + (wm * 32 + 8 * g + 4 * lh) * 2;
+                *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v;
+            }
+        }
+        // the 2 h2 border rows only feed outputs outside the stored window, but must be finite: zero both planes
+        for (int i = tid; i < 2 * pp.h2 * (4 * C / 16); i += 256) {
+            const int br = i / (4 * C / 16), c16 = i % (4 * C / 16);
+            const int row = br < pp.h2 ? br : NT + br;
+            uint4 z = {0u, 0u, 0u, 0u};
+            *(uint4*)(Xb + row * RSB + c16 * 16) = z;
+        }
+    }
+    const float u2 = p.wh_scale * sy;
+    acc_init(LEAN ? p.bias : pp.b1, u2);
+    ev_lds_barrier();
+
+    // ---------------- phase 2: c2 over the LDS-resident y1 (tap offset t reads rows r + h2 + t)
+    kloop(rW2, tlv2, ng2, Xb + (wn * (TN * 32) + li + pp.h2) * RSB + 16 * lh);
+    {
+        const float inv2 = 1.0f / u2;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r16 = 0; r16 < 16; ++r16) acc[0][j][r16] *= inv2;
+    }
     conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
 }
 

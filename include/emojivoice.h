@@ -169,18 +169,19 @@ int ev_profile_read(ev_handle *h, double *conv_ms, double *conv_flops, int64_t *
  * resblock_pair_split_kernel: every fp32 product as six exact bf16 products, fp32 accumulation); call before a resetting
  * ev_profile_read.  The rest of the family runs on v_mfma_f32_32x32x2_f32. */
 int ev_profile_read_split(ev_handle *h, double *ms, double *flops, int64_t *launches);
-/* Arithmetic of the contractions.  Tensors are fp32 and every accumulation is fp32 in either setting.
- *   6 (default): layers deep enough to pay for it form each fp32 product from six exact bf16 x bf16 products on the bf16 matrix pipe
- *                (the operand is the exact sum of three bf16 pieces; what the six products leave out is below 2^-24 |a b|, one fp32
- *                rounding) — errors indistinguishable from an fp32 FMA chain, ~1.45x the throughput at batch 64
- *   0:           every layer on the fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain)
- *   3:           opt-in fast setting of the vocoder's deep layers (conv_split_kernel, resblock_pair_split_kernel): the three products
- *                of weight <= 1, ~16 significand bits per product (dot products of length 1408: 8.9e-5 max relative error against
- *                3.4e-6).  HiFi-GAN at batch 64: 61 ms against 97 (6) and 154 (0); waveform RMS difference to the fp32 MFMA result
- *                7e-5 (6: 1.8e-6), i.e. inside the 1e-3 gate but NOT fp32-grade — never the default, never what bench.py times
- *   9:           accuracy A/B of conv_split_kernel only (tools/bf16_split_probe.hip); the other split builds run 6
+/* Arithmetic of the contractions.  Tensors are fp32 and every accumulation is fp32 in every setting.
+ *   16 (default): layers deep enough to pay for it form each fp32 product from THREE fp16 x fp16 products on the fp16 matrix pipe: an
+ *                 operand, times a power-of-two block scale (weights: one per layer; activations: one per workgroup tile, from the
+ *                 tile's maximum), is cut into two fp16 pieces h0 + h1 (22-23 significand bits), the product is h0 g0 + h0 g1 + h1 g0.
+ *                 Errors against fp64 at the level of the fp32 FMA chain (one conv layer, tools/arith_accuracy.py: rms 3.4e-7 of the
+ *                 output scale against 5.4e-7 for the fp32 MFMA), independent of the activations' scale; ~2.1x the fp32 MFMA's throughput
+ *   6:            three bf16 pieces per operand (exact split, no range handling), the six products of weight <= 2: fp32-grade too, ~1.45x
+ *   0:            every layer on the fp32 MFMA (v_mfma_f32_32x32x2_f32, bit-identical to an fmaf chain)
+ *   3:            opt-in fast bf16 setting of the vocoder's deep layers: three products of weight <= 1, ~16 significand bits per product
+ *                 (waveform RMS difference to the fp32 MFMA result 7e-5 against 1.7e-6 for 16 and 6): inside the 1e-3 gate, NOT fp32-grade
+ *   9:            accuracy A/B of conv_split_kernel only (tools/bf16_split_probe.hip); the other split builds run 6
  * The environment variable EV_SPLIT presets it for handles created afterwards.  Takes effect with the next call on the handle. */
-int ev_set_arithmetic(ev_handle *h, int bf16_products);
+int ev_set_arithmetic(ev_handle *h, int setting);
 int ev_get_arithmetic(ev_handle *h);
 
 /* Test hook: the build the last conv / fused-pair launch of this handle took (tile configuration id: 40 / 60 = conv_split_kernel /

@@ -74,8 +74,9 @@ def test_split_pieces_are_exact(eng):
 def test_conv1d_split_builds(eng, B, Cin, T, Cout, K, dil, slope, cfg):
     """conv_split_kernel (cfg 40: deep grids) and conv_split_bal_kernel (cfg 60: a few rounds of workgroups): fp32 convs whose products
     are formed on the bf16 matrix pipe — every fp32 operand is the exact sum of three bf16 pieces, the six products of weight <= 2 are
-    accumulated in fp32 (what is left out is below one fp32 rounding of the product: tools/bf16_split_probe.hip).  Same tolerance
-    against torch's fp32 conv as the fp32-MFMA builds, and bit-reproducible."""
+    accumulated in fp32 (what is left out is below one fp32 rounding of the product: tools/bf16_split_probe.hip) — and their fp16 forms
+    conv_h16_kernel (46) / conv_h16_bal_kernel (66): two block-scaled fp16 pieces, three products (the default).  Same tolerance against
+    torch's fp32 conv as the fp32-MFMA builds, and bit-reproducible."""
     g = torch.Generator().manual_seed(B + Cin + T)
     x = torch.randn(B, Cin, T, generator=g) * 1.5
     x[:, :, ::7] *= 1e-3                                   # operands of very different magnitude in one dot product
@@ -84,10 +85,16 @@ def test_conv1d_split_builds(eng, B, Cin, T, Cout, K, dil, slope, cfg):
     pad = dil * (K - 1) // 2
     xin = F.leaky_relu(x, slope) if slope >= 0 else x
     ref = F.conv1d(xin, w, b, padding=pad, dilation=dil)
-    got = eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope)
-    assert eng.last_cfg() == cfg, f"this shape was expected to take build {cfg}, took {eng.last_cfg()}"
-    _close(got, ref, what=f"split conv {Cin}->{Cout} k{K} d{dil}")
-    assert torch.equal(eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope), got)
+    orig = eng.arithmetic()
+    try:
+        for arith, want in ((6, cfg), (16, cfg + 6)):
+            eng.set_arithmetic(arith)
+            got = eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope)
+            assert eng.last_cfg() == want, f"this shape was expected to take build {want}, took {eng.last_cfg()}"
+            _close(got, ref, what=f"split conv {Cin}->{Cout} k{K} d{dil}, arithmetic {arith}")
+            assert torch.equal(eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope), got)
+    finally:
+        eng.set_arithmetic(orig)
 
 
 @pytest.mark.parametrize("B,Cin,T,Cout,K,slope", [(64, 256, 196, 256, 3, -1.0), (64, 256, 194, 256, 3, 0.1), (64, 512, 196, 256, 1, -1.0), (48, 256, 283, 256, 3, -1.0)])
@@ -145,18 +152,23 @@ def test_arithmetic_switch_in_process(eng):
     x = torch.randn(4, 128, 33000, generator=g)
     w = torch.randn(128, 128, 7, generator=g) / (128 * 7) ** 0.5
     b = torch.randn(128, generator=g)
-    assert eng.arithmetic() == 6
+    orig = eng.arithmetic()
+    eng.set_arithmetic(6)
     y6 = eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1)
     assert eng.last_cfg() == 40
     try:
+        eng.set_arithmetic(16)
+        y16 = eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1)
+        assert eng.last_cfg() == 46
+        assert torch.equal(eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1), y16)
         eng.set_arithmetic(0)
         y0 = eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1)
         assert eng.last_cfg() not in (40, 41, 60)
         assert torch.equal(eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1), y0)
     finally:
-        eng.set_arithmetic(6)
+        eng.set_arithmetic(orig)
     _close(y6, y0, rtol=1e-5, what="bf16-split products vs fp32 MFMA")
-    assert torch.equal(eng.op_conv1d(x.cuda(), w, b, dilation=3, padding=9, pre_lrelu_slope=0.1), y6)
+    _close(y16, y0, rtol=1e-5, what="fp16 block-scaled products vs fp32 MFMA")
     with pytest.raises(Exception):
         eng.set_arithmetic(4)
 
@@ -166,6 +178,7 @@ def test_split_builds_match_fp32_mfma_on_random_shapes(eng):
     with and without the prologue leaky-relu) that land on conv_split_kernel (40), its 64-channel tile (41) or the balanced grid (60)."""
     rng = torch.Generator().manual_seed(2024)
     seen = set()
+    orig = eng.arithmetic()
     for case in range(14):
         cin = [64, 128, 256, 512][int(torch.randint(0, 4, (1,), generator=rng))]
         cout = [64, 128, 192, 256, 512][int(torch.randint(0, 5, (1,), generator=rng))]
@@ -180,20 +193,22 @@ def test_split_builds_match_fp32_mfma_on_random_shapes(eng):
         w = torch.randn(cout, cin, K, generator=rng) / (cin * K) ** 0.5
         b = torch.randn(cout, generator=rng)
         pad = dil * (K - 1) // 2
-        y6 = eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope)
-        cfg = eng.last_cfg()
-        seen.add(cfg)
         try:
             eng.set_arithmetic(0)
             y0 = eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope)
-            assert eng.last_cfg() not in (40, 41, 60)
+            assert eng.last_cfg() not in (40, 41, 60, 46, 47, 66)
+            for arith in (6, 16):
+                eng.set_arithmetic(arith)
+                y = eng.op_conv1d(x.cuda(), w, b, dilation=dil, padding=pad, pre_lrelu_slope=slope)
+                cfg = eng.last_cfg()
+                seen.add(cfg)
+                if cfg in (40, 41, 60, 46, 47, 66):
+                    _close(y, y0, rtol=1e-5, what=f"case {case}: {cin}->{cout} k{K} d{dil} T{T} cfg {cfg}")
+                else:
+                    assert torch.equal(y, y0), f"case {case}: both settings took the fp32 build {cfg} and must agree bit for bit"
         finally:
-            eng.set_arithmetic(6)
-        if cfg in (40, 41, 60):
-            _close(y6, y0, rtol=1e-5, what=f"case {case}: {cin}->{cout} k{K} d{dil} T{T} cfg {cfg}")
-        else:
-            assert torch.equal(y6, y0), f"case {case}: both settings took the fp32 build {cfg} and must agree bit for bit"
-    assert {40, 41, 60} <= seen, f"the shapes were meant to cover all three split builds, saw {sorted(seen)}"
+            eng.set_arithmetic(orig)
+    assert {40, 41, 60, 46, 47, 66} <= seen, f"the shapes were meant to cover all split builds, saw {sorted(seen)}"
 
 
 def test_conv_transpose1d_split_build(eng):
@@ -205,9 +220,15 @@ def test_conv_transpose1d_split_build(eng):
     w = torch.randn(Cin, Cout, K, generator=g) / (Cin * K / s) ** 0.5
     b = torch.randn(Cout, generator=g)
     ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=s, padding=p)
-    got = eng.op_conv1d(x.cuda(), w, b, transposed=True, stride=s, padding=p, pre_lrelu_slope=0.1)
-    assert eng.last_cfg() == 41, eng.last_cfg()
-    _close(got, ref, what="convT 128->64 k4 s2, split build")
+    orig = eng.arithmetic()
+    try:
+        for arith, want in ((6, 41), (16, 47)):
+            eng.set_arithmetic(arith)
+            got = eng.op_conv1d(x.cuda(), w, b, transposed=True, stride=s, padding=p, pre_lrelu_slope=0.1)
+            assert eng.last_cfg() == want, eng.last_cfg()
+            _close(got, ref, what=f"convT 128->64 k4 s2, split build, arithmetic {arith}")
+    finally:
+        eng.set_arithmetic(orig)
 
 
 def test_conv_stride2(eng):

@@ -123,6 +123,8 @@ def test_hifigan_arithmetic_switch(vocoder, B, T):
     deep enough) and on the fp32 MFMA (ev_set_arithmetic 0): odd lengths, ragged last tiles; the two agree far inside the waveform gate."""
     g = torch.Generator().manual_seed(T + B)
     mel = (torch.randn(B, 80, T, generator=g) * 2.0 - 5.0).cuda()
+    orig = vocoder.engine.arithmetic()
+    vocoder.engine.set_arithmetic(6)
     w6 = vocoder(mel)
     assert torch.equal(vocoder(mel), w6)
     try:
@@ -130,8 +132,12 @@ def test_hifigan_arithmetic_switch(vocoder, B, T):
         w0 = vocoder(mel)
         vocoder.engine.set_arithmetic(3)                   # the opt-in fast setting: three products per fp32 product (~16 significand bits)
         w3 = vocoder(mel)
+        vocoder.engine.set_arithmetic(16)                  # two block-scaled fp16 pieces, three products: fp32-grade like 6
+        w16 = vocoder(mel)
+        assert torch.equal(vocoder(mel), w16)
     finally:
-        vocoder.engine.set_arithmetic(6)
+        vocoder.engine.set_arithmetic(orig)
+    assert float((w16 - w0).abs().max()) <= 5e-5 and float((w16 - w0).pow(2).mean().sqrt()) <= WAV_RMS_GATE / 100
     assert float(w0.abs().max()) > 1e-3
     assert float((w6 - w0).abs().max()) <= 5e-5 and float((w6 - w0).pow(2).mean().sqrt()) <= WAV_RMS_GATE / 100
     # not the default and not what bench.py times: inside the waveform gate with a margin of ~10, two orders above the default's error

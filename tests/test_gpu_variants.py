@@ -41,7 +41,7 @@ torch.save({"mel": mel.cpu(), "wav": wav.cpu()}, sys.argv[1])
 
 VARIANTS = [{"EV_KB": "2"}, {"EV_NO_LEAN": "1"}, {"EV_FUSE_PAIRS": "0"}, {"EV_FORCE_CFG": "0"}, {"EV_FORCE_CFG": "5"}, {"EV_FORCE_CFG": "6"},
             {"EV_FORCE_CFG": "4"}, {"EV_FUSE_MLP_MIN": "1"}, {"EV_FUSE_MLP": "0"}, {"EV_NO_ATTN_SK": "1"},
-            {"EV_MRF_STREAMS_MAX": "0"}, {"EV_FULL_REZERO": "1"}, {"EV_SPLIT": "0"}]
+            {"EV_MRF_STREAMS_MAX": "0"}, {"EV_FULL_REZERO": "1"}, {"EV_SPLIT": "0"}, {"EV_SPLIT": "6"}]
 
 
 # the single-utterance builds: conv_sk32_kernel, per-tile GroupNorm statistics + groupnorm_apply_kernel, split-key attention
@@ -92,7 +92,7 @@ def test_batch64_balanced_builds(tmp_path):
     nowait = _run(tmp_path, "b64_nowait", {"EV_SK_SPIN": "0"}, "b64")
     assert torch.equal(nowait["mel"], ref["mel"]) and torch.equal(nowait["wav"], ref["wav"])
     # (run-to-run equality of the default build is covered in-process by tests/test_gpu_ops.py; every switch here costs a batch-64 child)
-    for i, extra in enumerate([{"EV_NO_SK_BALANCE": "1"}, {"EV_CONV_BALANCE_W": "1", "EV_BAL5": "64"}, {"EV_FUSE_ATTN": "0", "EV_SK_WGS": "3"}, {"EV_SPLIT": "0"}]):
+    for i, extra in enumerate([{"EV_NO_SK_BALANCE": "1"}, {"EV_CONV_BALANCE_W": "1", "EV_BAL5": "64"}, {"EV_FUSE_ATTN": "0", "EV_SK_WGS": "3"}, {"EV_SPLIT": "0"}, {"EV_SPLIT": "6"}]):
         got = _run(tmp_path, f"b64_v{i}", extra, "b64")
         dmel = float((got["mel"] - ref["mel"]).abs().max())
         dwav = float((got["wav"] - ref["wav"]).abs().max())
