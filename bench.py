@@ -628,7 +628,7 @@ def main():
         path_roof = {"mfma_frac": round(per_gpu * ALG_FLOP_PER_AUDIO_S / (peak_split * 1e12), 4),
                      "fp32_mfma_equiv": round(per_gpu * ALG_FLOP_PER_AUDIO_S / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4),
                      "hbm_frac": round(per_gpu * ALG_BYTES_PER_AUDIO_S / (PEAK_HBM_GBS * 1e9), 4),
-                     "note": "whole-path fractions from SURVEY §8(d) per-audio-second work: against the split builds' roof (bf16 peak / 6), against the "
+                     "note": "whole-path fractions from SURVEY §8(d) per-audio-second work: against the split builds' roof (16-bit MFMA peak / products per multiply-add), against the "
                              "fp32 MFMA peak (> 1 = faster than any exact-fp32-MFMA implementation could be), and against HBM"}
         # stage times of one batch (serial schedule) and the latency a single request sees
         torch.cuda.synchronize()

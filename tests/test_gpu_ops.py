@@ -173,6 +173,31 @@ def test_arithmetic_switch_in_process(eng):
         eng.set_arithmetic(4)
 
 
+def test_h16_block_scaling_is_scale_invariant(eng):
+    """The fp16 form (arithmetic 16) has fp16's range only through its power-of-two block scales: a deep conv layer against fp64 with
+    activations that are tiny, huge, and of very different scale from utterance to utterance and from channel to channel — the error,
+    relative to each utterance's output RMS, stays at the level of the fp32 FMA chain in every case (tools/arith_accuracy.py prints the
+    same table for all settings)."""
+    g = torch.Generator().manual_seed(5)
+    B, C, T, K, d = 3, 128, 50000, 7, 3
+    w = torch.randn(C, C, K, generator=g) / (C * K) ** 0.5
+    b = torch.randn(C, generator=g) * 0.1
+    base = torch.randn(B, C, T, generator=g)
+    cases = {"unit": base, "tiny": base * 1e-4, "huge": base * 3e3, "rows": base * torch.tensor([1e-3, 1.0, 1e3]).view(3, 1, 1),
+             "channels": base * (10.0 ** torch.linspace(-3, 3, C)).view(1, C, 1)}
+    orig = eng.arithmetic()
+    try:
+        eng.set_arithmetic(16)
+        for name, x in cases.items():
+            ref = F.conv1d(F.leaky_relu(x.double(), 0.1), w.double(), b.double(), padding=d * (K - 1) // 2, dilation=d)
+            y = eng.op_conv1d(x.cuda(), w, b, dilation=d, padding=d * (K - 1) // 2, pre_lrelu_slope=0.1).cpu().double()
+            assert eng.last_cfg() == 46
+            e = (y - ref).abs() / ref.pow(2).mean(dim=(1, 2), keepdim=True).sqrt()
+            assert float(e.max()) <= 2e-5 and float(e.pow(2).mean().sqrt()) <= 1.5e-6, (name, float(e.max()), float(e.pow(2).mean().sqrt()))
+    finally:
+        eng.set_arithmetic(orig)
+
+
 def test_split_builds_match_fp32_mfma_on_random_shapes(eng):
     """Differential test of the two datapaths on one handle: random layer shapes (channels, taps, dilations, odd lengths, ragged last tiles,
     with and without the prologue leaky-relu) that land on conv_split_kernel (40), its 64-channel tile (41) or the balanced grid (60)."""

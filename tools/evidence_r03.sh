@@ -10,8 +10,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE 
 python tools/traffic_summary.py $O/fetch $O/write 2 > $O/traffic.json 2>&1
 python tools/shape_profile.py 64 $O/shape.txt > $O/shape.log 2>&1
 EV_SPLIT=0 python tools/shape_profile.py 64 $O/shape_fp32.txt > $O/shape_fp32.log 2>&1
+EV_SPLIT=6 python tools/shape_profile.py 64 $O/shape_bf16x6.txt > $O/shape_bf16x6.log 2>&1
+EV_SPLIT=6 python bench.py --no-extras --no-cpu-baseline > $O/bench_bf16x6.json 2> $O/bench_bf16x6.err
+python tools/arith_accuracy.py > $O/arith_accuracy.txt 2>&1
 EV_SPLIT=0 python bench.py --no-extras --no-cpu-baseline > $O/bench_fp32_mfma.json 2> $O/bench_fp32_mfma.err
-SHAPES="L1,L2" python tools/conv_bench.py 0:0 0:40 4:40 8:40 64:40 > $O/conv_split_ablation.txt 2>&1
+SHAPES="L1,L2" B=64 python tools/conv_bench.py 0:0 0:49 0:40 0:46 0:43 > $O/conv_split_ablation.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --config 4 --steps 3 > $O/config4.json 2> $O/config4.err
 python bench.py --config 5 > $O/config5.json 2> $O/config5.err
