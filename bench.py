@@ -28,7 +28,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 de
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak
 ARITH = int(os.environ.get("EV_SPLIT") or 16)   # ev_set_arithmetic preset of the handles this process creates
 # products per fp32 multiply-add of the deep layers: 16 -> three fp16 x fp16 products of two block-scaled fp16 pieces (default), 6 / 3 / 9 ->
-# bf16 pieces; the U-Net feed-forward runs the six-product bf16 form under 16 too
+# bf16 pieces
 SPLIT_PRODUCTS = {16: 3, 6: 6, 3: 3, 9: 9}.get(ARITH, 3)
 # fp32 in, fp32 out, fp32 accumulation everywhere; the deep layers form each fp32 product from 16-bit pieces on the fp16 / bf16 matrix pipe
 # (fp32-grade: tools/arith_accuracy.py, tools/bf16_split_probe.hip), the rest runs on the fp32 MFMA.  EV_SPLIT=0: everything on the fp32 MFMA.
@@ -599,12 +599,12 @@ def main():
             ach_split = sp_fl / (sp_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach_split, 2), "peak": round(peak_split, 1), "unit": "TFLOP/s", "frac": round(ach_split / peak_split, 4),
                         "traffic": traffic,
-                        "kernel": ("conv_h16_kernel + conv_h16_bal_kernel + resblock_pair_h16_kernel (fp32 contractions as 3 fp16 products of two block-scaled fp16 "
-                                   "pieces per operand on v_mfma_f32_32x32x16_f16, fp32 accumulation) + ln_mlp_split_kernel (6 bf16 products)") if ARITH == 16 else
+                        "kernel": ("conv_h16_kernel + conv_h16_bal_kernel + resblock_pair_h16_kernel + ln_mlp_h16_kernel (fp32 contractions as 3 fp16 products of two "
+                                   "block-scaled fp16 pieces per operand on v_mfma_f32_32x32x16_f16, fp32 accumulation)") if ARITH == 16 else
                                   ("conv_split_kernel + conv_split_bal_kernel + resblock_pair_split_kernel + ln_mlp_split_kernel (fp32 contractions as "
                                    f"{SPLIT_PRODUCTS} bf16 products per element pair on v_mfma_f32_32x32x16_bf16, fp32 accumulation)"),
                         "peak_note": f"2500 TFLOP/s dense 16-bit MFMA / {SPLIT_PRODUCTS} products per fp32 multiply-add; `achieved` counts ALGORITHMIC fp32 FLOP"
-                                     + (" (the feed-forward launches, 60 of them, execute 6 products: their share of `executed_tflops` is under-counted)" if ARITH == 16 else ""),
+                                     ,
                         "executed_tflops": round(ach_split * SPLIT_PRODUCTS, 1), "peak_executed": PEAK_BF16_MFMA_TFLOPS,
                         "sustained_note": "with real operand data the pure 16-bit MFMA loop is power-limited to ~1800 TFLOP/s (1.4 kW, clock 2.4 -> ~1.78 GHz: "
                                           "tools/bf16_split_probe.hip, profiles/r03_clock_and_power_vocoder_loop.txt), i.e. ~600 TFLOP/s of fp32-equivalent work at 3 "

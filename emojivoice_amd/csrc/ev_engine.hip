@@ -1071,11 +1071,14 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
             if (ensure_sk(h)) return 1;
             const long U = (long)nt64 * nchunk;
             const int grid = h->ncu;
+            const bool h16 = split_terms == 16 && L1.Wh && L2->Wh;
             mp.W1x = L1.Wx; mp.W2x = L2->Wx; mp.ntiles = nt64;
+            mp.W1h = L1.Wh; mp.W2h = L2->Wh; mp.w1_scale = L1.wh_scale; mp.w2_scale = L2->wh_scale;
             mp.sk.q = (int)(U / grid); mp.sk.r = (int)(U % grid); mp.sk.spin_limit = h->sk_spin;
             mp.sk.ctrl = h->sk_ctrl; mp.sk.flags = h->sk_ctrl + 16; mp.sk.part = h->sk_part; mp.sk.part_floats = EV_SK_PART_FLOATS;
             if (L1.Mpad > 1024) return fail(h, "launch_mlp: hidden width %d > 1024 (LDS table of the SnakeBeta vectors)", L1.Mpad);
-            const size_t smem = (size_t)64 * (6 * 256 + 16) + (size_t)64 * (6 * 128 + 16) + 16 + (size_t)2 * L1.Mpad * sizeof(float);
+            const size_t smem = h16 ? (size_t)64 * (4 * 256 + 16) + (size_t)64 * (4 * 128 + 16) + 16 + (size_t)2 * L1.Mpad * sizeof(float) + 32
+                                    : (size_t)64 * (6 * 256 + 16) + (size_t)64 * (6 * 128 + 16) + 16 + (size_t)2 * L1.Mpad * sizeof(float);
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->prof) {
                 if (h->ev_used + 2 > h->ev_pool.size()) {
@@ -1084,7 +1087,7 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
                 e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
                 HIPCHK(h, hipEventRecord(e0, h->stream));
             }
-            ensure_dyn_smem<ln_mlp_split_kernel<6>>(smem, h->device);
+            if (h16) ensure_dyn_smem<ln_mlp_h16_kernel<0>>(smem, h->device); else ensure_dyn_smem<ln_mlp_split_kernel<6>>(smem, h->device);
             static const char* stamp_file = getenv("EV_MLP_STAMPS");     // diagnostic: phase stamps of a few workgroups of the first launches
             static int stamped = 0;
             if (stamp_file && *stamp_file && stamped < 2) {
@@ -1092,7 +1095,8 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
                 HIPCHK(h, hipMalloc((void**)&d, (size_t)grid * 32 * sizeof(unsigned long long)));
                 HIPCHK(h, hipMemsetAsync(d, 0, (size_t)grid * 32 * sizeof(unsigned long long), h->stream));
                 mp.ep.stamps = d;
-                hipLaunchKernelGGL((ln_mlp_split_kernel<6>), dim3(grid), dim3(256), smem, h->stream, mp);
+                if (h16) hipLaunchKernelGGL((ln_mlp_h16_kernel<0>), dim3(grid), dim3(256), smem, h->stream, mp);
+                else hipLaunchKernelGGL((ln_mlp_split_kernel<6>), dim3(grid), dim3(256), smem, h->stream, mp);
                 HIPCHK(h, hipStreamSynchronize(h->stream));
                 std::vector<unsigned long long> st((size_t)grid * 32);
                 HIPCHK(h, hipMemcpy(st.data(), d, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1109,8 +1113,8 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
                     fclose(f);
                 }
                 ++stamped;
-            } else
-            hipLaunchKernelGGL((ln_mlp_split_kernel<6>), dim3(grid), dim3(256), smem, h->stream, mp);
+            } else if (h16) hipLaunchKernelGGL((ln_mlp_h16_kernel<0>), dim3(grid), dim3(256), smem, h->stream, mp);
+            else hipLaunchKernelGGL((ln_mlp_split_kernel<6>), dim3(grid), dim3(256), smem, h->stream, mp);
             HIPCHK(h, hipGetLastError());
             if (h->prof) {
                 HIPCHK(h, hipEventRecord(e1, h->stream));
@@ -1118,7 +1122,7 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
                 const double fl = 2.0 * (L1.macs_per_row + L2->macs_per_row) * valid_rows;
                 h->prof_flops += fl;
                 h->prof_launches += 1;
-                h->prof_recs.push_back({2, 256, Lout.Cout, 1, g.nrows, 120, 1, fl});
+                h->prof_recs.push_back({2, 256, Lout.Cout, 1, g.nrows, h16 ? 121 : 120, 1, fl});
             }
             return 0;
         }
@@ -2487,7 +2491,7 @@ int ev_profile_read_split(ev_handle* h, double* ms_out, double* flops_out, int64
     if (h->prof_recs.size() * 2 == h->ev_used)
         for (size_t i = 0; i < h->prof_recs.size(); ++i) {
             const auto& r = h->prof_recs[i];
-            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 46 || r.cfg == 47 || r.cfg == 66 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && r.cfg == 120);
+            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 46 || r.cfg == 47 || r.cfg == 66 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && (r.cfg == 120 || r.cfg == 121));
             if (!split) continue;
             float t = 0;
             HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));

@@ -3195,6 +3195,7 @@ struct MlpParams {
     const float* W1; const float* b1; int M1;        // fragment order [M1/32][256/8][64][4]; M1 a multiple of 128
     const float* alpha; const float* binv;           // SnakeBeta vectors over the hidden width (MODE 0)
     const float* W2;                                 // fragment order [256/32][M1/8][64][4] (MODE 0)
+    const void* W1h; const void* W2h; float w1_scale, w2_scale;   // ln_mlp_h16_kernel: both linears times their power-of-two scale as two fp16 pieces
     const void* W1x; const void* W2x;                // ln_mlp_split_kernel: both linears as three bf16 pieces (conv_split_kernel's fragment order)
     int ntiles;                    // 32-row tiles of the launch; the grid is either ntiles workgroups (one tile each: sk.q = M1 / 128,
     SkCtl sk;                      // sk.r = 0, no hand-offs) or the balanced persistent grid described at SkCtl
@@ -3813,6 +3814,382 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_split_kernel(const MlpParams mp
                     ev_lds_barrier();
                     stamp();
                 }
+            }
+            auto acc_io = [&](unsigned base, int mode) {    // mode 0: store (write-through), 1: add from memory
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned off = base + pelem + (unsigned)((a * 2 + j) * 4 + q) * 1024u;
+                            if (mode == 0) {
+                                const f32x4 v = {acc2[a][j][4 * q], acc2[a][j][4 * q + 1], acc2[a][j][4 * q + 2], acc2[a][j][4 * q + 3]};
+                                ev_bstore4_sc1(rPart, off, v);
+                            } else {
+                                const f32x4 v = ev_bload4_sc1(rPart, off);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) acc2[a][j][4 * q + e] += v[e];
+                            }
+                        }
+            };
+            if (spilled) { acc_io((unsigned)g * pslot + pslot / 2, 1); spilled = false; }
+            if (c0 != 0) {                             // not the owner: publish the partial tile (no bias) and move on
+                acc_io((unsigned)g * pslot, 0);
+                pend_pub = true;
+                break;
+            }
+            bool again = false;
+            while (c1 < nchunk) {                      // owner: add the contributors' partials in ascending workgroup order
+                int n = 0;
+                while (n < 64 && gi + n < (int)gridDim.x && sk_start(mp.sk, gi + n) < tile_end) ++n;
+                if (n == 0) break;
+                const int ready = sk_wait_many(mp.sk, gi, n, tag, tid, skw);
+                for (int k = 0; k < ready; ++k) acc_io((unsigned)(gi + k) * pslot, 1);
+                gi += ready;
+                if (ready < n) {                       // gi is not there in time: spill the running sum, compute its share here
+                    const int sgi = sk_start(mp.sk, gi);
+                    int egi = sk_start(mp.sk, gi + 1);
+                    egi = egi < tile_end ? egi : tile_end;
+                    acc_io((unsigned)g * pslot + pslot / 2, 0);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    cA = sgi - t * nchunk; cB = egi - t * nchunk;
+                    spilled = true; again = true;
+                    ++gi;
+                    break;
+                }
+            }
+            if (again) {
+                const int ht0 = cA * 4 + wave;
+                ldP(R0, ht0, 0); ldP(R1, ht0, 1); ldP(R2, ht0, 2); ldP(R3, ht0, 3); ldP(R4, ht0, 4); ldP(R5, ht0, 5); ldP(R6, ht0, 6); ldP(R7, ht0, 7);
+                continue;
+            }
+            // ---- epilogue: + residual, * mask, store (its first barrier also retires the last phase 2's LDS reads)
+            conv_epilogue_lean<2, 2, 1>(p, acc2, smem + wave * (32 * 68), wave * 64, n0, lane);
+            break;
+        }
+    }
+    if (pend_pub) sk_publish(mp.sk, g, tag, tid);
+    sk_arrive(mp.sk, tag, tid);
+}
+
+// ---------------------------------------------------------------------------
+// ln_mlp_h16_kernel: ln_mlp_split_kernel in the fp16 form of conv_h16_kernel (two block-scaled fp16 pieces per operand, three products).
+// Scales: the two linears' weight scales from the loader; sx from the maximum of the normalised 64 x 256 tile (one more LDS exchange in the
+// staging); one scale per hidden chunk from the maximum of SnakeBeta over the workgroup's 64 x 128 values, exchanged at the barrier the
+// plane write has anyway.  The hidden values wait in registers in true units until that scale is known; the phase-2 accumulators are
+// rescaled (exact power of two) when the chunk scale changes and return to true units at the end of a pass.
+// ---------------------------------------------------------------------------
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) {
+    constexpr int NT = 64, C = 256, HC = 128;
+    constexpr int XRS = 4 * C + 16, HRS = 4 * HC + 16;   // LDS row strides in bytes: two fp16 planes (65 x 16, 33 x 16)
+    const ConvParams& p = mp.ep;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;                             // [NT][XRS]: LN(x) times the tile scale as two fp16 planes
+    char* Hb = Xb + NT * XRS;                           // [NT][HRS]: SnakeBeta(hidden chunk) times the chunk scale as two fp16 planes
+    int* skw = (int*)(Hb + NT * HRS);
+    float* Sv = (float*)(Hb + NT * HRS + 16);          // SnakeBeta vectors over the hidden width: [alpha (M1) | 1 / beta (M1)], M1 <= 1024
+    float* red = Sv + 2 * mp.M1;                       // the waves' maxima: [0..3] of the normalised rows, [4..7] of a hidden chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(mp.X), rW1 = ev_rsrc(mp.W1h), rW2 = ev_rsrc(mp.W2h);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int nchunk = mp.M1 / HC;
+    const int KS2 = mp.M1 / 16;                         // slabs per 32-row tile of W2
+    const int g = blockIdx.x;
+    const unsigned tag = sk_tag(mp.sk);
+    int u = sk_start(mp.sk, g);
+    const int ue = sk_start(mp.sk, g + 1);
+    f32x4 R0[2], R1[2], R2[2], R3[2], R4[2], R5[2], R6[2], R7[2];
+    auto ldP = [&](f32x4 (&dst)[2], int ht, int sl) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) dst[pc] = ev_bload4(rW1, wlane, (unsigned)(((ht * (C / 16) + sl) * 2 + pc) * 1024));
+    };
+    auto ldQ = [&](f32x4 (&dst)[2], int hc, int sl, int a) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) dst[pc] = ev_bload4(rW2, wlane, (unsigned)((((wave * 2 + a) * KS2 + hc * (HC / 16) + sl) * 2 + pc) * 1024));
+    };
+    const __amdgpu_buffer_rsrc_t rB1 = ev_rsrc(mp.b1);
+    // ring set i of the phase that comes next, whichever it is (no load under a branch): phase 1 of hidden tile hx -> slab i of W1's
+    // row tile hx; phase 2 of chunk hx -> slab i / 2 of W2's row tile 2 wave + (i & 1)
+    auto ldN = [&](f32x4 (&dst)[2], bool q2, int hx, int i) {
+        const __amdgpu_buffer_rsrc_t rs = q2 ? rW2 : rW1;
+        const unsigned off = q2 ? (unsigned)((((wave * 2 + (i & 1)) * KS2 + hx * (HC / 16) + (i >> 1)) * 2) * 1024) : (unsigned)(((hx * (C / 16) + i) * 2) * 1024);
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) dst[pc] = ev_bload4(rs, wlane, off + (unsigned)(pc * 1024));
+    };
+    {   // (all loads first: one latency episode; published by the first staging barrier)
+        float va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = q * 256 + tid; va[q] = i < mp.M1 ? mp.alpha[i] : 0.f; vb[q] = i < mp.M1 ? mp.binv[i] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int i = q * 256 + tid; if (i < mp.M1) { Sv[i] = va[q]; Sv[mp.M1 + i] = vb[q]; } }
+    }
+    const unsigned coff = (unsigned)(4 * lh) * 4u;
+    const char* xrow = Xb + li * XRS + 16 * lh;
+    const char* hrow = Hb + li * HRS + 16 * lh;
+    const __amdgpu_buffer_rsrc_t rPart = ev_rsrc(mp.sk.part);
+    const unsigned pslot = (unsigned)mp.sk.part_floats * 8u;
+    const unsigned pelem = (unsigned)(wave * 16) * 1024u + wlane;      // element (wave, a, j, q) of a partial tile = 64 lanes x 16 B
+    bool pend_pub = false;
+    int nst = 0;                                       // diagnostic (EV_MLP_STAMPS): up to 32 s_memrealtime stamps per workgroup
+    auto stamp = [&]() { if (p.stamps && tid == 0 && nst < 32) p.stamps[32 * g + nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
+    stamp();
+    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+
+    while (u < ue) {
+        const int t = u / nchunk, c0 = u - t * nchunk;
+        const int c1 = (ue - u < nchunk - c0) ? c0 + (ue - u) : nchunk;
+        u += c1 - c0;
+        const int n0 = t * NT;
+        {   // tiles that contain no storable row (pure padding) do nothing — owner and contributors agree, the test only reads t
+            int t_first = (n0 % p.S) - p.P;
+            int dist;
+            if (t_first >= 0 && t_first < p.T) dist = 0;
+            else if (t_first < 0) dist = -t_first;
+            else dist = p.S - (n0 % p.S) + p.P;
+            if (dist >= NT || n0 + dist >= p.nrows) continue;
+        }
+        {
+            const int ht0 = c0 * 4 + wave;
+            ldP(R0, ht0, 0); ldP(R1, ht0, 1); ldP(R2, ht0, 2); ldP(R3, ht0, 3); ldP(R4, ht0, 4); ldP(R5, ht0, 5); ldP(R6, ht0, 6); ldP(R7, ht0, 7);
+        }
+        ev_lds_barrier();                              // the previous segment's epilogue is done with its LDS slabs
+        float sx;
+        {   // ---- stage + LayerNorm + split: wave w owns rows 16 w .. 16 w + 15, a row = 4 channels per lane
+            const f32x4 gm = *(const f32x4*)(mp.ln_g + lane * 4), be = *(const f32x4*)(mp.ln_b + lane * 4);
+            f32x4 xv[16];                               // all sixteen rows requested at once: one latency episode
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = n0 + wave * 16 + r;
+                xv[r] = ev_bload4(rX, ((unsigned)(gr < p.nrows ? gr : 0) * mp.ldx + lane * 4) * 4u, 0);   // (beyond the tensor: pad row 0)
+            }
+            float mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                xv[r] = ev_ln256_row(xv[r], gm, be, mp.ln_eps);
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xv[r][0]), fabsf(xv[r][1]))), fmaxf(fabsf(xv[r][2]), fabsf(xv[r][3])));
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if (lane == 0) red[wave] = mx;
+            ev_lds_barrier();
+            sx = evh_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));   // the tile's activation scale (conv_h16_kernel)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                uint2 q0v, q1v;
+                evh_split4(xv[r] * sx, q0v, q1v);
+                char* dst = Xb + (wave * 16 + r) * XRS + lane * 8;
+                *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v;
+            }
+        }
+        if (pend_pub) { sk_publish(mp.sk, g, tag, tid); pend_pub = false; }   // (drain + barrier + flag: the barrier also publishes the staged rows)
+        else ev_lds_barrier();
+        stamp();
+
+        int cA = c0, cB = c1;
+        bool spilled = false;
+        int gi = g + 1;
+        const int tile_end = (t + 1) * nchunk;
+        for (;;) {
+            // accumulator units (all powers of two): phase 1 runs in w1_scale * sx; phase 2 in w2_scale * (scale of the hidden chunk whose
+            // planes are in LDS) — acc2 is rescaled when that changes and brought back to true units at the end of the pass
+            const float u1 = mp.w1_scale * sx, inv1 = 1.0f / u1;
+            float cur_unit = mp.w2_scale, sh_lds = 1.f;
+            f32x16 acc2[2][2];                         // this wave's 64 output channels x 64 rows, alive across all chunks of the pass
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+                    if (p.bias && cA == 0) bq = *(const f32x4*)(p.bias + wave * 64 + a * 32 + 8 * q + 4 * lh) * cur_unit;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc2[a][j][4 * q + e] = bq[e];
+                }
+            f32x4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = ev_bload4(rB1, coff + (unsigned)((cA * 4 + wave) * 32 + 8 * q) * 4u, 0);
+            // Software pipeline over the chunks: phase 1 of chunk hc, then phase 2 of chunk hc - 1 with the SnakeBeta + split arithmetic of
+            // chunk hc in the shadow of its MFMAs (one wave per SIMD: nothing else would fill the matrix pipe during ~800 vector
+            // instructions), then the pieces go to LDS between two barriers.  One more phase 2 after the loop.
+            f32x4 hvs[8];                              // chunk hc's hidden values in true units, (j, q) -> 4 channels
+            float hmax = 0.f;
+            f32x4 B0[2][2], B1[2][2];
+            auto ldBh = [&](f32x4 (&dst)[2][2], int sl) {
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) dst[pc][j] = *(const f32x4*)(hrow + j * 32 * HRS + pc * (2 * HC) + sl * 32);
+            };
+            auto mma2 = [&](const f32x4 (&a0)[2], const f32x4 (&a1)[2], const f32x4 (&b)[2][2]) {
+#pragma unroll
+                for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc2[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a0[PA[tt]]), __builtin_bit_cast(f16x8, b[PB[tt]][j]), acc2[0][j], 0, 0, 0);
+                        acc2[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[PA[tt]]), __builtin_bit_cast(f16x8, b[PB[tt]][j]), acc2[1][j], 0, 0, 0);
+                    }
+            };
+            for (int hc = cA; hc <= cB; ++hc) {
+                const bool p1 = hc < cB, p2 = hc > cA;             // phase 1 of chunk hc / phase 2 of chunk hc - 1 in this iteration
+                const int ht = (p1 ? hc : cA) * 4 + wave;          // (past the last chunk: harmless re-reads)
+                const int htn = hc + 1 < cB ? ht + 4 : cA * 4 + wave;
+                // (two partial accumulators per row tile = four accumulation chains for a wave that is alone on its SIMD; tools/mfma_chain_probe.hip
+                // prices two against four chains at 344 vs 315 ns per slab of this loop)
+                f32x16 acc1[2], acc1b[2];
+                if (p1) {
+                    // ================= phase 1: acc1 = W1[ht] . LN(x) + b1, K = 256 = 16 slabs; the ring holds slabs 0..7 of ht =================
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { acc1[j][4 * q + e] = bq[q][e] * u1; acc1b[j][4 * q + e] = 0.f; }
+                    auto ldB = [&](f32x4 (&dst)[2][2], int sl) {
+#pragma unroll
+                        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) dst[pc][j] = *(const f32x4*)(xrow + j * 32 * XRS + pc * (2 * C) + sl * 32);
+                    };
+                    auto mma1 = [&](const f32x4 (&a)[2], const f32x4 (&b)[2][2]) {
+#pragma unroll
+                        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j) {
+                                if (tt & 1) acc1b[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[PA[tt]]), __builtin_bit_cast(f16x8, b[PB[tt]][j]), acc1b[j], 0, 0, 0);
+                                else acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[PA[tt]]), __builtin_bit_cast(f16x8, b[PB[tt]][j]), acc1[j], 0, 0, 0);
+                            }
+                    };
+                    const int hq2 = p2 ? hc - 1 : hc;              // the phase 2 that follows: the previous chunk's (first iteration: none — re-reads)
+                    // One wave per SIMD: nothing hides a block of loads between two blocks of MFMAs.  The loads of a step — the B fragments of
+                    // the next slab and the refill of the ring set consumed one step EARLIER (its registers are free) — are interleaved with
+                    // the step's MFMAs by an explicit schedule (sched_group_barrier: 2 MFMAs, 1 LDS read, [1 fragment load]).  The set
+                    // consumed by a phase's last step is refilled by the first step of whatever phase comes next (sets 6 and 7: a re-load of
+                    // what is already there is harmless).  Per-phase stamps (EV_MLP_STAMPS, profiles/r03_ln_mlp_split_stamps.txt): 3.9 us per
+                    // phase 1 = 245 ns per slab, where twelve MFMAs alone take 219 ns at the clock the chip holds under bf16 MFMA load
+                    // (tools/mfma_chain_probe.hip: 18.3 ns each, i.e. 32 cycles at ~1.75 GHz) and the probe's loop with the same loads 315 ns.
+                    const bool nq1 = p2 || hc + 1 >= cB;                       // what follows this phase 1: a phase 2 (of chunk nx1) or the next chunk's phase 1
+                    const int nx1 = p2 ? hq2 : (hc + 1 < cB ? ht + 4 : hc);
+                    ldB(B0, 0);
+#define EVX_P1(RR, BC, BN_, SL, REFILL, NV)                                                       \
+                    ldB(BN_, ((SL) + 1) & 15);                                                    \
+                    REFILL;                                                                       \
+                    mma1(RR, BC);                                                                \
+                    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                            \
+                        if (i_ < 3) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);            \
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        \
+                        if (i_ < (NV)) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);         \
+                    }                                                                             \
+                    __builtin_amdgcn_sched_barrier(0);
+                    EVX_P1(R0, B0, B1, 0, ldP(R6, ht, 6); ldP(R7, ht, 7), 4)
+                    EVX_P1(R1, B1, B0, 1, ldP(R0, ht, 8), 2)   EVX_P1(R2, B0, B1, 2, ldP(R1, ht, 9), 2)   EVX_P1(R3, B1, B0, 3, ldP(R2, ht, 10), 2)
+                    EVX_P1(R4, B0, B1, 4, ldP(R3, ht, 11), 2)  EVX_P1(R5, B1, B0, 5, ldP(R4, ht, 12), 2)  EVX_P1(R6, B0, B1, 6, ldP(R5, ht, 13), 2)
+                    EVX_P1(R7, B1, B0, 7, ldP(R6, ht, 14), 2)  EVX_P1(R0, B0, B1, 8, ldP(R7, ht, 15), 2)
+                    // from here on the ring goes over to what comes next (set i of it)
+                    EVX_P1(R1, B1, B0, 9, ldN(R0, nq1, nx1, 0), 2)   EVX_P1(R2, B0, B1, 10, ldN(R1, nq1, nx1, 1), 2)  EVX_P1(R3, B1, B0, 11, ldN(R2, nq1, nx1, 2), 2)
+                    EVX_P1(R4, B0, B1, 12, ldN(R3, nq1, nx1, 3), 2)  EVX_P1(R5, B1, B0, 13, ldN(R4, nq1, nx1, 4), 2)  EVX_P1(R6, B0, B1, 14, ldN(R5, nq1, nx1, 5), 2)
+                    EVX_P1(R7, B1, B0, 15, ldN(R6, nq1, nx1, 6), 2)
+#undef EVX_P1
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc1[j] = (acc1[j] + acc1b[j]) * inv1;      // back to true units
+                    stamp();
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[q] = ev_bload4(rB1, coff + (unsigned)(htn * 32 + 8 * q) * 4u, 0);   // next chunk's bias
+                }
+                // SnakeBeta + split of (row tile j, register group q) of chunk hc: C/D register 4 q + e is hidden channel 8 q + 4 half + e
+                auto snake = [&](int jq) {
+                    const int j = jq >> 2, q = jq & 3;
+                    const f32x4 saq = *(const f32x4*)(Sv + ht * 32 + 8 * q + 4 * lh), sbq = *(const f32x4*)(Sv + mp.M1 + ht * 32 + 8 * q + 4 * lh);
+                    f32x4 hv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float v = acc1[j][4 * q + e]; hv[e] = fmaf(sbq[e], ev_sin2(v * saq[e]), v); }
+                    hvs[jq] = hv;
+                    hmax = fmaxf(fmaxf(hmax, fmaxf(fabsf(hv[0]), fabsf(hv[1]))), fmaxf(fabsf(hv[2]), fabsf(hv[3])));
+                };
+                auto phase2 = [&](auto with_snake) {
+                    constexpr bool WS = decltype(with_snake)::value;     // (a template parameter, not a branch: the vector arithmetic must sit in the MFMAs' basic block)
+                    // ================= phase 2 of chunk hc - 1: acc2 += W2[64 channels of this wave][chunk] . h, K = 128 = 8 slabs;
+                    // one (j, q) group of chunk hc's SnakeBeta per slab in the MFMAs' shadow =================
+                    const int hp = hc - 1;
+                    // what comes next: phase 1 of chunk hc + 1; after the last phase 1 of the pass the phase 2 of chunk hc; after the
+                    // last phase 2 nothing (a harmless re-read)
+                    const bool nq = p1 && hc + 1 >= cB;
+                    const int nx = hc + 1 < cB ? ht + 4 : (p1 ? hc : cA * 4 + wave);
+                    {   // the planes in LDS carry the scale sh_lds: bring the running sums to that unit
+                        const float nu = mp.w2_scale * sh_lds, f = nu / cur_unit;
+                        cur_unit = nu;
+#pragma unroll
+                        for (int a = 0; a < 2; ++a)
+#pragma unroll
+                            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc2[a][j][r] *= f;
+                    }
+                    ldBh(B0, 0);
+#define EVX_P2(RA, RB, BC, BN_, SL, REFILL)                                                       \
+                    ldBh(BN_, ((SL) + 1) & 7);                                                    \
+                    REFILL;                                                                       \
+                    mma2(RA, RB, BC);                                                            \
+                    if constexpr (WS) {                                                           \
+                        snake(SL);                                                                \
+                        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                        \
+                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                    \
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    \
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                    \
+                            __builtin_amdgcn_sched_group_barrier(0x002, 30, 0);                   \
+                        }                                                                         \
+                    } else {                                                                      \
+                        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                        \
+                            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                    \
+                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                    \
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                    \
+                        }                                                                         \
+                    }                                                                             \
+                    __builtin_amdgcn_sched_barrier(0);
+                    EVX_P2(R0, R1, B0, B1, 0, ldN(R6, true, hp, 6); ldN(R7, true, hp, 7))
+                    EVX_P2(R2, R3, B1, B0, 1, ldQ(R0, hp, 4, 0); ldQ(R1, hp, 4, 1))  EVX_P2(R4, R5, B0, B1, 2, ldQ(R2, hp, 5, 0); ldQ(R3, hp, 5, 1))
+                    EVX_P2(R6, R7, B1, B0, 3, ldQ(R4, hp, 6, 0); ldQ(R5, hp, 6, 1))  EVX_P2(R0, R1, B0, B1, 4, ldQ(R6, hp, 7, 0); ldQ(R7, hp, 7, 1))
+                    // from here on the ring goes over to what comes next (sets 6 and 7: by that phase's first step)
+                    EVX_P2(R2, R3, B1, B0, 5, ldN(R0, nq, nx, 0); ldN(R1, nq, nx, 1))  EVX_P2(R4, R5, B0, B1, 6, ldN(R2, nq, nx, 2); ldN(R3, nq, nx, 3))
+                    EVX_P2(R6, R7, B1, B0, 7, ldN(R4, nq, nx, 4); ldN(R5, nq, nx, 5))
+#undef EVX_P2
+                };
+                if (p2) { if (p1) phase2(std::true_type{}); else phase2(std::false_type{}); }
+                else if (p1) {
+#pragma unroll
+                    for (int jq = 0; jq < 8; ++jq) snake(jq);
+                }
+                stamp();
+                if (p1) {
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) hmax = fmaxf(hmax, __shfl_xor(hmax, o, 64));
+                    if (lane == 0) red[4 + wave] = hmax;
+                    hmax = 0.f;
+                    ev_lds_barrier();        // every wave is done reading the previous chunk's planes (its phase 2); the waves' maxima are published
+                    sh_lds = evh_scale_for(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));   // this chunk's scale
+#pragma unroll
+                    for (int jq = 0; jq < 8; ++jq) {
+                        uint2 q0v, q1v;
+                        evh_split4(hvs[jq] * sh_lds, q0v, q1v);
+                        char* dst = Hb + ((jq >> 2) * 32 + li) * HRS + (wave * 32 + 8 * (jq & 3) + 4 * lh) * 2;
+                        *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * HC) = q1v;
+                    }
+                    ev_lds_barrier();
+                    stamp();
+                }
+            }
+            {   // back to true units: partial tiles are handed over, spilled and stored in them
+                const float f = 1.0f / cur_unit;
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc2[a][j][r] *= f;
             }
             auto acc_io = [&](unsigned base, int mode) {    // mode 0: store (write-through), 1: add from memory
 #pragma unroll
