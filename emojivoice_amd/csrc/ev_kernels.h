@@ -1356,7 +1356,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
     float xs;
     {
         float mx = 0.f;
-        for (int ch = 0; ch < nchunks; ++ch) {
+        for (int ch = 0; ch < ((p.dbg & 2048) ? 0 : nchunks); ++ch) {      // (dbg 2048: tools/conv_bench.py ablation — no pre-scan, a fixed scale of 1024)
             const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
 #pragma unroll
             for (int q0 = 0; q0 < XPASS; q0 += XG) {
@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
         if (lane == 0) red[wave] = mx;
         ev_lds_barrier();
         mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        xs = evh_scale_for(mx);
+        xs = (p.dbg & 2048) ? 1024.f : evh_scale_for(mx);
     }
     const float acc_in = p.wh_scale * xs;              // bias in accumulator units
     const float acc_out = 1.0f / acc_in;               // (both powers of two: exact)
