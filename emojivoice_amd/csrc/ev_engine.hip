@@ -228,7 +228,7 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
         for (float w : Wh) if (std::isfinite(w)) mx = std::max(mx, std::fabs(w));
         int k = 0;
         if (mx > 0.f) { int ex; std::frexp(mx, &ex); k = 14 - ex; }          // mx = m * 2^ex, m in [0.5, 1): mx * 2^(14 - ex) in [8192, 16384)
-        k = std::max(-100, std::min(100, k));
+        k = std::max(-40, std::min(40, k));                                  // (the product with an activation scale of up to 2^40 must stay far from the fp32 range)
         L.wh_scale = std::ldexp(1.0f, k);
         const int MT32 = L.Mpad / 32, KG16 = L.Kpad / 16;
         std::vector<unsigned short> Whp(Wh.size() * 2);

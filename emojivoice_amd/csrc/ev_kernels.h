@@ -1265,7 +1265,9 @@ __device__ __forceinline__ void evh_split4(const f32x4 v, uint2& q0, uint2& q1) 
 __device__ __forceinline__ float evh_scale_for(float mx) {
     const int ex = (int)((__float_as_uint(mx) >> 23) & 255u);          // biased exponent of max
     if (ex == 0 || ex == 255) return 1.f;
-    return __uint_as_float((unsigned)(127 + 13 - (ex - 127)) << 23);   // 2^(13 - floor(log2 max))
+    const int e2 = 267 - ex;                                            // biased exponent of 2^(13 - floor(log2 max))
+    return __uint_as_float((unsigned)(e2 > 167 ? 167 : e2) << 23);      // (at most 2^40: a tile whose maximum is below 2^-27 is ~0 beside the bias, and the
+                                                                        // product of the two scales must stay far from the fp32 range)
 }
 template <int TM, int TN>
 __device__ __forceinline__ void evh_mma(f32x16 (&acc)[TM][TN], const f32x4 (&a)[2][TM], const f32x4 (&b)[2][TN]) {

@@ -183,7 +183,7 @@ def test_h16_block_scaling_is_scale_invariant(eng):
     w = torch.randn(C, C, K, generator=g) / (C * K) ** 0.5
     b = torch.randn(C, generator=g) * 0.1
     base = torch.randn(B, C, T, generator=g)
-    cases = {"unit": base, "tiny": base * 1e-4, "huge": base * 3e3, "rows": base * torch.tensor([1e-3, 1.0, 1e3]).view(3, 1, 1),
+    cases = {"unit": base, "tiny": base * 1e-4, "huge": base * 3e3, "beyond fp16": base * 1e7, "rows": base * torch.tensor([1e-3, 1.0, 1e3]).view(3, 1, 1),
              "channels": base * (10.0 ** torch.linspace(-3, 3, C)).view(1, C, 1)}
     orig = eng.arithmetic()
     try:
@@ -194,6 +194,10 @@ def test_h16_block_scaling_is_scale_invariant(eng):
             assert eng.last_cfg() == 46
             e = (y - ref).abs() / ref.pow(2).mean(dim=(1, 2), keepdim=True).sqrt()
             assert float(e.max()) <= 2e-5 and float(e.pow(2).mean().sqrt()) <= 1.5e-6, (name, float(e.max()), float(e.pow(2).mean().sqrt()))
+        # degenerate tiles: all zeros and vanishingly small activations give the bias (no NaN from the scale arithmetic)
+        for x in (torch.zeros(B, C, T), base * 1e-36):
+            y = eng.op_conv1d(x.cuda(), w, b, dilation=d, padding=d * (K - 1) // 2, pre_lrelu_slope=0.1).cpu()
+            assert bool(torch.isfinite(y).all()) and float((y - b.view(1, C, 1)).abs().max()) <= 1e-6
     finally:
         eng.set_arithmetic(orig)
 
