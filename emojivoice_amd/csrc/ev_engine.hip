@@ -158,7 +158,7 @@ struct ev_handle {
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
     bool sk_spread = false;         // EV_SK_SPREAD=1: launches of fewer row tiles than CUs (small batches) spread their units over up to 2 x CUs workgroups
     int sk_wgs = 2;                 // EV_SK_WGS=<1..3>: persistent workgroups per CU of a balanced ln_mlp launch (A/B runs)
-    int sk_spin = 20000;            // EV_SK_SPIN=<polls> before an owner recomputes a contributor's share itself (~1.5 us per poll)
+    int sk_spin = 3000;             // EV_SK_SPIN=<polls> before an owner recomputes a contributor's share itself (~1.5 us per poll: at most ~4.5 ms)
     int mrf_max_frames = 16384;     // EV_MRF_STREAMS_MAX=<B*T mel frames>: calls up to this size use the three streams (0 = never).  Six more scratch
                                     // tensors per level; at batch 64 x 516 frames (21 GB) the two-stage pipeline of bench.py already fills the gaps:
                                     // -1.4 % on the vocoder alone, +0.6 % on the pipelined step
