@@ -49,7 +49,7 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 2
+#define EV_ABI_VERSION 3   /* 3: ev_set_arithmetic / ev_get_arithmetic, ev_profile_read_split, test hooks; everything of version 2 unchanged */
 
 typedef struct ev_handle ev_handle;
 

@@ -30,7 +30,7 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), f"{n} declared in include/emojivoice.h but not exported"
     assert set(names) == set(_lib.EXPORTS)
     lib.ev_abi_version.restype = ctypes.c_int
-    assert lib.ev_abi_version() == 2
+    assert lib.ev_abi_version() == 3
 
 
 def test_no_cpu_fallback():
