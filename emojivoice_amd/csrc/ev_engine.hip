@@ -526,7 +526,7 @@ void launch_h16(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
 inline bool split_ok(const ConvLayer& L, const ConvParams& p0) {
     ConvParams p = p0;
     p.dbg &= ~4;                                        // (the no-epilogue ablation of tools/conv_bench.py exists in this build too)
-    return L.Wx && lean_ok(p) && p.isplit_log2 >= 31 && L.Cin % EVX_KC == 0 && L.Cin == L.Kpad && L.Mpad % 128 == 0 && ((size_t)p.bias & 15) == 0;
+    return L.Wx && lean_ok(p) && (p.isplit_log2 >= 31 || (p.isplit_log2 >= 6 && p.isplit_log2 < 31)) && L.Cin % EVX_KC == 0 && L.Cin == L.Kpad && L.Mpad % 128 == 0 && ((size_t)p.bias & 15) == 0;
 }
 
 // small-launch builds (conv_gemm_sk_kernel): 64 x 64 tiles, 16 waves, K split four ways inside the workgroup (TW = 4, KS = 4),

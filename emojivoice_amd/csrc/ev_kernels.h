@@ -799,6 +799,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define EVX_KC 64                           // input channels per LDS stage
 #define EVX_RSB (3 * EVX_KC * 2 + 16)       // LDS row stride in bytes (400 = 25 x 16)
+// byte offset of the 64-channel chunk `ch` inside an input row: channel c lives at (c >> isplit_log2) * isstride + (c & (2^isplit_log2 - 1))
+// (the pair view of a strided slice: the stride-2 down conv reads rows of 2 C channels whose halves lie isstride apart; no split: 2^31)
+__device__ __forceinline__ unsigned evx_chunk_off(const ConvParams& p, int ch) {
+    const int c0 = ch * EVX_KC;
+    return ((unsigned)(c0 >> p.isplit_log2) * (unsigned)p.isstride + (unsigned)(c0 & ((1 << p.isplit_log2) - 1))) * 4u;
+}
 // three bf16 pieces of four fp32 values, packed as the four channels' bf16 in channel order (8 bytes per piece)
 __device__ __forceinline__ void evx_split4(const f32x4 v, uint2& q0, uint2& q1, uint2& q2) {
     unsigned u[4], w[4];
@@ -932,7 +938,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(const ConvParams p) 
         __builtin_amdgcn_s_setprio(3);
         if (!(p.dbg & 8)) ev_lds_barrier();             // the previous chunk's MFMAs are done with the tile
         if (!(p.dbg & 64) || ch == 0) {                 // (dbg 64: stage the first chunk only — timing ablation)
-            const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+            const unsigned soff = evx_chunk_off(p, ch);
 #pragma unroll
             for (int q0 = 0; q0 < XPASS; q0 += XG) {
                 if (q0 * RPS >= xrows) continue;
@@ -1359,7 +1365,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
     {
         float mx = 0.f;
         for (int ch = 0; ch < ((p.dbg & 2048) ? 0 : nchunks); ++ch) {      // (dbg 2048: tools/conv_bench.py ablation — no pre-scan, a fixed scale of 1024)
-            const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+            const unsigned soff = evx_chunk_off(p, ch);
 #pragma unroll
             for (int q0 = 0; q0 < XPASS; q0 += XG) {
                 if (q0 * RPS >= xrows) continue;
@@ -1401,7 +1407,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
         __builtin_amdgcn_s_setprio(3);
         ev_lds_barrier();                               // the previous chunk's MFMAs are done with the tile
         {
-            const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+            const unsigned soff = evx_chunk_off(p, ch);
 #pragma unroll
             for (int q0 = 0; q0 < XPASS; q0 += XG) {
                 if (q0 * RPS >= xrows) continue;
@@ -1576,7 +1582,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams
                 __builtin_amdgcn_s_setprio(3);
                 ev_lds_barrier();                          // the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
                 {
-                    const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+                    const unsigned soff = evx_chunk_off(p, ch);
 #pragma unroll
                     for (int q0 = 0; q0 < XPASS; q0 += XG) {
                         if (q0 * RPS >= xrows) continue;
@@ -1777,7 +1783,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
             {
                 float mx = 0.f;
                 for (int ch = cA; ch < cB; ++ch) {
-                    const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+                    const unsigned soff = evx_chunk_off(p, ch);
 #pragma unroll
                     for (int q0 = 0; q0 < XPASS; q0 += XG) {
                         if (q0 * RPS >= xrows) continue;
@@ -1820,7 +1826,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
                 __builtin_amdgcn_s_setprio(3);
                 ev_lds_barrier();                          // the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
                 {
-                    const unsigned soff = (unsigned)(ch * EVX_KC) * 4u;
+                    const unsigned soff = evx_chunk_off(p, ch);
 #pragma unroll
                     for (int q0 = 0; q0 < XPASS; q0 += XG) {
                         if (q0 * RPS >= xrows) continue;
