@@ -468,8 +468,8 @@ inline bool lean_acc(const ConvParams& p) { return p.accum || p.div3 || p.act2_l
 inline bool lean_ok(const ConvParams& p) {
     if (lean_acc(p) && (!p.R || p.act != ACT_NONE)) return false;
     return (p.act == ACT_NONE || p.act == ACT_LRELU || (p.act == ACT_SNAKE && (((size_t)p.act_a | (size_t)p.act_b) & 15) == 0)) &&
-           ((!p.mask1 && !p.mask2) || (p.rowmask && p.mmul == 1 && !(p.mask2 && lean_acc(p)))) && p.scale == 1.f &&
-           !p.Y2 && p.osplit_log2 >= 31 && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (!p.R || (p.ldr & 3) == 0) &&
+           ((!p.mask1 && !p.mask2) || (p.rowmask && p.mmul >= 1 && !(p.mask2 && lean_acc(p)))) && p.scale == 1.f &&
+           !p.Y2 && (p.osplit_log2 >= 31 || (p.osplit_log2 >= 2 && (p.osstride & 3) == 0)) && (p.Cout & 3) == 0 && (p.ldy & 3) == 0 && (!p.R || (p.ldr & 3) == 0) &&
            (!p.bias || ((size_t)p.bias & 15) == 0) && !(p.dbg & 4) && p.S >= 4;   // (lean row walk: two wraps per 8-row pass)
 }
 template <int BM, int BN, int WM, int WN, bool PF = false>

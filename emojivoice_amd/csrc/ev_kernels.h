@@ -335,7 +335,12 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     int t = n0l % p.S;
     if (t < 0) t += p.S;                              // (only the fused pair kernel starts before row 0)
     t -= p.P;
-    unsigned yoff = ((unsigned)n0l * p.ldy + co) * 4u, roff = ((unsigned)n0l * p.ldr + co) * 4u;
+    // (output column split — the pair view a stride-2 transposed conv writes: logical channel co lives at column
+    // (co >> osplit_log2) * osstride + (co & (2^osplit_log2 - 1)), and its mask row is n * mmul + (co >> osplit_log2); a lane's four
+    // channels never straddle a split)
+    const int sp = (p.osplit_log2 >= 31) ? 0 : (co >> p.osplit_log2);
+    const unsigned col = (p.osplit_log2 >= 31) ? (unsigned)co : (unsigned)sp * (unsigned)p.osstride + (unsigned)(co & ((1 << p.osplit_log2) - 1));
+    unsigned yoff = ((unsigned)n0l * p.ldy + col) * 4u, roff = ((unsigned)n0l * p.ldr + col) * 4u;
     const unsigned ystep = (unsigned)(RPP * p.ldy) * 4u, rstep = (unsigned)(RPP * p.ldr) * 4u;
     // ONE register set for the residual / running-sum / mask rows of a slab: row q of slab j+1 is requested right after row q
     // of slab j has been consumed, so a whole slab of loads is still in flight while the current slab is transposed and stored
@@ -356,7 +361,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
     auto issue_one = [&](int q) {                      // next row of the walk (nn / ro / ao advance with it) into slot q
         const bool inr = co_ok && nn >= 0 && nn < p.nrows;
         rr[q] = ev_bload4(rRe, (has_r && inr) ? ro : 0u, 0);
-        rmk[q] = ev_bload1(rMe, (mk && inr) ? (unsigned)nn * 4u : 0u, 0);
+        rmk[q] = ev_bload1(rMe, (mk && inr) ? ((unsigned)nn * (unsigned)p.mmul + (unsigned)sp) * 4u : 0u, 0);
         if constexpr (ACC) {
             ra[q] = ev_bload4(rY, (use_acc && inr) ? ao : 0u, 0);
             ao += ystep;
