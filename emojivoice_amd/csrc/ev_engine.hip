@@ -1127,6 +1127,34 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
             return 0;
         }
     }
+    {   // LayerNorm + QKV of a large batch on the fp16 pipe: one workgroup per 64-row tile (ln_qkv_h16_kernel)
+        static const bool no_qkv_h16 = getenv("EV_NO_QKV_H16") != nullptr;
+        const int nt64 = (g.nrows + 63) / 64;
+        if (mode == 1 && h->split_terms == 16 && !no_qkv_h16 && L1.Wh && L1.Mpad == 384 && !R && !rowmask && h->ncu > 0 && nt64 >= h->ncu) {
+            mp.W1h = L1.Wh; mp.w1_scale = L1.wh_scale; mp.ntiles = nt64;
+            const size_t smem = (size_t)64 * (4 * 256 + 16) + 16;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->prof) {
+                if (h->ev_used + 2 > h->ev_pool.size()) {
+                    for (int i = 0; i < 64; ++i) { hipEvent_t ev; HIPCHK(h, hipEventCreate(&ev)); h->ev_pool.push_back(ev); }
+                }
+                e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
+                HIPCHK(h, hipEventRecord(e0, h->stream));
+            }
+            ensure_dyn_smem<ln_qkv_h16_kernel>(smem, h->device);
+            hipLaunchKernelGGL(ln_qkv_h16_kernel, dim3(nt64), dim3(256), smem, h->stream, mp);
+            HIPCHK(h, hipGetLastError());
+            if (h->prof) {
+                HIPCHK(h, hipEventRecord(e1, h->stream));
+                const double valid_rows = (double)(g.nrows / g.S) * g.T;
+                const double fl = 2.0 * L1.macs_per_row * valid_rows;
+                h->prof_flops += fl;
+                h->prof_launches += 1;
+                h->prof_recs.push_back({3, 256, Lout.Cout, 1, g.nrows, 122, 1, fl});
+            }
+            return 0;
+        }
+    }
     const int ntiles = (g.nrows + 31) / 32;
     size_t smem = (size_t)(32 * 260 + 4 * 32 * 36 + 4) * sizeof(float);
     // Balanced persistent grid (SkCtl): three workgroups per CU — the LDS request is padded so that exactly three fit, i.e. every
@@ -2491,7 +2519,7 @@ int ev_profile_read_split(ev_handle* h, double* ms_out, double* flops_out, int64
     if (h->prof_recs.size() * 2 == h->ev_used)
         for (size_t i = 0; i < h->prof_recs.size(); ++i) {
             const auto& r = h->prof_recs[i];
-            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 46 || r.cfg == 47 || r.cfg == 66 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && (r.cfg == 120 || r.cfg == 121));
+            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 46 || r.cfg == 47 || r.cfg == 66 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && (r.cfg == 120 || r.cfg == 121)) || (r.kind == 3 && r.cfg == 122);
             if (!split) continue;
             float t = 0;
             HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));

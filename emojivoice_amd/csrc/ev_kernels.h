@@ -4263,6 +4263,134 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
 }
 
 // ---------------------------------------------------------------------------
+// ln_qkv_h16_kernel: MODE 1 of ln_mlp_kernel (y = Wqkv . LN(x) [+ b1], transformer.py:262-271) in the fp16 form of conv_h16_kernel, for
+// the projection width 384 = 2 heads x 64 x {q, k, v}.  One workgroup per 64-row tile: rows staged once, normalised and split in
+// registers (the staging of ln_mlp_h16_kernel, tile scale from the maximum of the normalised rows), then each wave runs its 96 output
+// channels (three 32-row weight tiles) x 64 rows over K = 256 = 16 slabs, three products per slab pair, weight fragments straight from
+// L2 two slabs ahead.  The accumulators run in units of w1_scale * sx and return to true units before the lean epilogue (two calls:
+// its lane map needs a channel count that divides 256).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) {
+    constexpr int NT = 64, C = 256, TM = 3;
+    constexpr int XRS = 4 * C + 16;
+    const ConvParams& p = mp.ep;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;                             // [NT][XRS]: LN(x) times the tile scale as two fp16 planes; later the epilogue slabs
+    float* red = (float*)(Xb + NT * XRS);               // the waves' maxima
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(mp.X), rW1 = ev_rsrc(mp.W1h), rB1 = ev_rsrc(mp.b1);
+    const unsigned wlane = (unsigned)lane * 16u;
+    const int n0 = blockIdx.x * NT;
+    {   // tiles that contain no storable row (pure padding) do nothing
+        int t_first = (n0 % p.S) - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - (n0 % p.S) + p.P;
+        if (dist >= NT || n0 + dist >= p.nrows) return;
+    }
+    // weight fragments: set s of the ring = slab (k 16 s .. 16 s + 15) of this wave's three row tiles, two pieces each
+    f32x4 A[3][TM][2];
+    auto ldA = [&](f32x4 (&dst)[TM][2], int sl) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) dst[i][pc] = ev_bload4(rW1, wlane, (unsigned)((((wave * TM + i) * (C / 16) + sl) * 2 + pc) * 1024));
+    };
+    ldA(A[0], 0); ldA(A[1], 1);
+    f32x4 bq[TM][4];
+    const unsigned coff = (unsigned)(4 * lh) * 4u;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) bq[i][q] = ev_bload4(rB1, coff + (unsigned)((wave * TM + i) * 32 + 8 * q) * 4u, 0);
+    float sx;
+    {   // ---- stage + LayerNorm + split: wave w owns rows 16 w .. 16 w + 15, a row = 4 channels per lane
+        const f32x4 gm = *(const f32x4*)(mp.ln_g + lane * 4), be = *(const f32x4*)(mp.ln_b + lane * 4);
+        f32x4 xv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int gr = n0 + wave * 16 + r;
+            xv[r] = ev_bload4(rX, ((unsigned)(gr < p.nrows ? gr : 0) * mp.ldx + lane * 4) * 4u, 0);   // (beyond the tensor: pad row 0)
+        }
+        float mx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            xv[r] = ev_ln256_row(xv[r], gm, be, mp.ln_eps);
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xv[r][0]), fabsf(xv[r][1]))), fmaxf(fabsf(xv[r][2]), fabsf(xv[r][3])));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) red[wave] = mx;
+        ev_lds_barrier();
+        sx = evh_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            uint2 q0v, q1v;
+            evh_split4(xv[r] * sx, q0v, q1v);
+            char* dst = Xb + (wave * 16 + r) * XRS + lane * 8;
+            *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v;
+        }
+    }
+    ev_lds_barrier();
+    const float u1 = mp.w1_scale * sx, inv1 = 1.0f / u1;
+    f32x16 acc[TM][2];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] = bq[i][q][e] * u1;
+    const char* xrow = Xb + li * XRS + 16 * lh;
+    f32x4 B[2][2][2];                                   // [ring][piece][row tile j]
+    auto ldB = [&](f32x4 (&dst)[2][2], int sl) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dst[pc][j] = *(const f32x4*)(xrow + j * 32 * XRS + pc * (2 * C) + sl * 32);
+    };
+    constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+    ldB(B[0], 0);
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) {
+        if (sl + 1 < 16) ldB(B[(sl + 1) & 1], sl + 1);
+        if (sl + 2 < 16) ldA(A[(sl + 2) % 3], sl + 2);
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[sl % 3][i][PA[tt]]), __builtin_bit_cast(f16x8, B[sl & 1][PB[tt]][j]), acc[i][j], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv1;
+    // ---- store (the epilogue's first barrier retires the K loop's LDS reads; its slabs lie in the dead X planes)
+    {
+        f32x16 a2[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) a2[i][j] = acc[i][j];
+        conv_epilogue_lean<2, 2, 1>(p, a2, smem + wave * (32 * 68), wave * 96, n0, lane);
+    }
+    {
+        f32x16 a1[1][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) a1[0][j] = acc[2][j];
+        conv_epilogue_lean<1, 2, 1>(p, a1, smem + wave * (32 * 68), wave * 96 + 64, n0, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Self-attention over mel frames, 64-dim heads, fp32 matrix cores, flash-style
 // online softmax.  Semantics of diffusers 0.25 Attention + SDPA with a FLOAT mask
 // (transformer.py:266-271): scores = q.k/8 + m[key], m = 1.0 for frames inside the

@@ -33,6 +33,15 @@ def test_header_symbols_exported():
     assert lib.ev_abi_version() == 3
 
 
+def test_driver_build_hook_accepts_the_library():
+    """__graft_entry__.build()'s post-compile check (ABI of the loaded library == the header's) — without the two-minute compile."""
+    import __graft_entry__ as entry
+
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build_library()
+    assert entry._check_abi(_lib.load_library()) == 3
+
+
 def test_no_cpu_fallback():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
