@@ -1144,6 +1144,7 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
             ensure_dyn_smem<ln_qkv_h16_kernel>(smem, h->device);
             hipLaunchKernelGGL(ln_qkv_h16_kernel, dim3(nt64), dim3(256), smem, h->stream, mp);
             HIPCHK(h, hipGetLastError());
+            h->last_cfg = 122;
             if (h->prof) {
                 HIPCHK(h, hipEventRecord(e1, h->stream));
                 const double valid_rows = (double)(g.nrows / g.S) * g.T;

@@ -4267,7 +4267,7 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
 // the projection width 384 = 2 heads x 64 x {q, k, v}.  One workgroup per 64-row tile: rows staged once, normalised and split in
 // registers (the staging of ln_mlp_h16_kernel, tile scale from the maximum of the normalised rows), then each wave runs its 96 output
 // channels (three 32-row weight tiles) x 64 rows over K = 256 = 16 slabs, three products per slab pair, weight fragments straight from
-// L2 two slabs ahead.  The accumulators run in units of w1_scale * sx and return to true units before the lean epilogue (two calls:
+// L2 three slabs ahead.  The accumulators run in units of w1_scale * sx and return to true units before the lean epilogue (two calls:
 // its lane map needs a channel count that divides 256).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) {
@@ -4292,14 +4292,14 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
         if (dist >= NT || n0 + dist >= p.nrows) return;
     }
     // weight fragments: set s of the ring = slab (k 16 s .. 16 s + 15) of this wave's three row tiles, two pieces each
-    f32x4 A[3][TM][2];
+    f32x4 A[4][TM][2];
     auto ldA = [&](f32x4 (&dst)[TM][2], int sl) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int pc = 0; pc < 2; ++pc) dst[i][pc] = ev_bload4(rW1, wlane, (unsigned)((((wave * TM + i) * (C / 16) + sl) * 2 + pc) * 1024));
     };
-    ldA(A[0], 0); ldA(A[1], 1);
+    ldA(A[0], 0); ldA(A[1], 1); ldA(A[2], 2);
     f32x4 bq[TM][4];
     const unsigned coff = (unsigned)(4 * lh) * 4u;
 #pragma unroll
@@ -4358,14 +4358,14 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) {
         if (sl + 1 < 16) ldB(B[(sl + 1) & 1], sl + 1);
-        if (sl + 2 < 16) ldA(A[(sl + 2) % 3], sl + 2);
+        if (sl + 3 < 16) ldA(A[(sl + 3) & 3], sl + 3);
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[sl % 3][i][PA[tt]]), __builtin_bit_cast(f16x8, B[sl & 1][PB[tt]][j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[sl & 3][i][PA[tt]]), __builtin_bit_cast(f16x8, B[sl & 1][PB[tt]][j]), acc[i][j], 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)

@@ -390,6 +390,21 @@ def test_ln_mlp_balanced_grid(eng, rows, monkeypatch):
         assert torch.equal(eng.op_ln_mlp(*args), got)
     wq = torch.randn(384, 256, generator=torch.Generator().manual_seed(1)) / 16.0
     _close(eng.op_ln_mlp(x.cuda(), ln_g.cuda(), ln_b.cuda(), wq, None), xn @ wq.T, what="balanced ln + qkv")
+    if rows >= 64 * 256 and eng.arithmetic() == 16:
+        # from one 64-row tile per CU up the 384-wide projection takes ln_qkv_h16_kernel (fp16 pieces, block-scaled); fp32-grade against
+        # fp64, with a bias, and with rows scaled far outside the fp16 range (LayerNorm removes the scale, the tile scale the rest)
+        assert eng.last_cfg() == 122
+        bq = torch.randn(384, generator=torch.Generator().manual_seed(2)) * 0.1
+        ref64 = F.layer_norm(x.double(), (256,), ln_g.double(), ln_b.double(), eps=1e-5) @ wq.double().T + bq.double()
+        got_q = eng.op_ln_mlp(x.cuda(), ln_g.cuda(), ln_b.cuda(), wq, bq)
+        assert eng.last_cfg() == 122
+        err = (got_q.cpu().double() - ref64).abs().max().item()
+        assert err <= 2e-5 * ref64.abs().max().item(), err
+        assert torch.equal(eng.op_ln_mlp(x.cuda(), ln_g.cuda(), ln_b.cuda(), wq, bq), got_q)
+        big_g = ln_g * 3.0e6
+        ref_big = F.layer_norm(x.double(), (256,), big_g.double(), ln_b.double(), eps=1e-5) @ wq.double().T
+        got_big = eng.op_ln_mlp(x.cuda(), big_g.cuda(), ln_b.cuda(), wq, None)
+        assert (got_big.cpu().double() - ref_big).abs().max().item() <= 2e-5 * ref_big.abs().max().item()
     monkeypatch.setenv("EV_SK_SPIN", "0")
     e2 = Engine(0)
     try:
