@@ -17,6 +17,8 @@ EV_SPLIT=0 python bench.py --no-extras --no-cpu-baseline > $O/bench_fp32_mfma.js
 SHAPES="L1,L2" B=64 python tools/conv_bench.py 0:0 0:49 0:40 0:46 0:43 > $O/conv_split_ablation.txt 2>&1
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --config 4 --steps 3 > $O/config4.json 2> $O/config4.err
+python tools/latency_split.py > $O/batch1_latency_split.txt 2>&1
+timeout -k 10 600 python tools/fuzz_h16.py 80 1 > $O/fuzz_h16.txt 2>&1
 python bench.py --config 5 > $O/config5.json 2> $O/config5.err
 find $O -name "*kernel_trace.csv" -size +2M -delete; find $O -name "*counter_collection.csv" -size +2M -delete
 ls -la $O $O/stats/* | head -40
