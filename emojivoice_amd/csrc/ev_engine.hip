@@ -1141,8 +1141,35 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
                 e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
                 HIPCHK(h, hipEventRecord(e0, h->stream));
             }
-            ensure_dyn_smem<ln_qkv_h16_kernel>(smem, h->device);
-            hipLaunchKernelGGL(ln_qkv_h16_kernel, dim3(nt64), dim3(256), smem, h->stream, mp);
+            ensure_dyn_smem<ln_qkv_h16_kernel<0>>(smem, h->device); ensure_dyn_smem<ln_qkv_h16_kernel<1>>(smem, h->device);
+            static const int qdbg = getenv("EV_QKV_DBG") ? atoi(getenv("EV_QKV_DBG")) : 0;
+            static const char* stamp_file = getenv("EV_QKV_STAMPS");     // diagnostic: phase stamps of a few workgroups of the first launches
+            static int stamped = 0;
+            if (stamp_file && *stamp_file && stamped < 4) {
+                unsigned long long* d = nullptr;
+                HIPCHK(h, hipMalloc((void**)&d, (size_t)nt64 * 8 * sizeof(unsigned long long)));
+                HIPCHK(h, hipMemsetAsync(d, 0, (size_t)nt64 * 8 * sizeof(unsigned long long), h->stream));
+                mp.ep.stamps = d;
+                { if (qdbg == 1) hipLaunchKernelGGL(ln_qkv_h16_kernel<1>, dim3(nt64), dim3(256), smem, h->stream, mp); else hipLaunchKernelGGL(ln_qkv_h16_kernel<0>, dim3(nt64), dim3(256), smem, h->stream, mp); }
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                std::vector<unsigned long long> st((size_t)nt64 * 8);
+                HIPCHK(h, hipMemcpy(st.data(), d, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                hipFree(d);
+                mp.ep.stamps = nullptr;
+                if (FILE* f = fopen(stamp_file, "a")) {
+                    unsigned long long t0 = ~0ull, t1 = 0;
+                    for (int w = 0; w < nt64; ++w) if (st[(size_t)w * 8]) { t0 = std::min(t0, st[(size_t)w * 8]); t1 = std::max(t1, st[(size_t)w * 8 + 5]); }
+                    fprintf(f, "## ln_qkv_h16_kernel rows=%d: %d workgroups, first start -> last end %.2f us; per workgroup: start offset | staged+LN | split+barrier | K loop | epilogue 1 | epilogue 2 (us)\n", g.nrows, nt64, (double)(t1 - t0) / 100.0);
+                    for (int w : {0, 1, 2, 100, 255, 256, 300, 511, 512, 519}) {
+                        if (w >= nt64 || !st[(size_t)w * 8]) continue;
+                        fprintf(f, "  wg %3d: +%.2f |", w, (double)(st[(size_t)w * 8] - t0) / 100.0);
+                        for (int k = 1; k < 6; ++k) fprintf(f, " %.2f", (double)(st[(size_t)w * 8 + k] - st[(size_t)w * 8 + k - 1]) / 100.0);
+                        fprintf(f, "\n");
+                    }
+                    fclose(f);
+                }
+                ++stamped;
+            } else { if (qdbg == 1) hipLaunchKernelGGL(ln_qkv_h16_kernel<1>, dim3(nt64), dim3(256), smem, h->stream, mp); else hipLaunchKernelGGL(ln_qkv_h16_kernel<0>, dim3(nt64), dim3(256), smem, h->stream, mp); }
             HIPCHK(h, hipGetLastError());
             h->last_cfg = 122;
             if (h->prof) {

@@ -4270,6 +4270,7 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
 // L2 three slabs ahead.  The accumulators run in units of w1_scale * sx and return to true units before the lean epilogue (two calls:
 // its lane map needs a channel count that divides 256).
 // ---------------------------------------------------------------------------
+template <int DBG = 0>   // diagnostic build (EV_QKV_DBG=1): no weight-fragment loads inside the K loop
 __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) {
     constexpr int NT = 64, C = 256, TM = 3;
     constexpr int XRS = 4 * C + 16;
@@ -4283,6 +4284,8 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
     const __amdgpu_buffer_rsrc_t rX = ev_rsrc(mp.X), rW1 = ev_rsrc(mp.W1h), rB1 = ev_rsrc(mp.b1);
     const unsigned wlane = (unsigned)lane * 16u;
     const int n0 = blockIdx.x * NT;
+    auto stamp = [&](int i) { if (p.stamps && tid == 0) p.stamps[8 * blockIdx.x + i] = __builtin_amdgcn_s_memrealtime(); };   // diagnostic (EV_QKV_STAMPS)
+    stamp(0);
     {   // tiles that contain no storable row (pure padding) do nothing
         int t_first = (n0 % p.S) - p.P;
         int dist;
@@ -4324,6 +4327,7 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
         if (lane == 0) red[wave] = mx;
+        stamp(1);
         ev_lds_barrier();
         sx = evh_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 #pragma unroll
@@ -4335,6 +4339,7 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
         }
     }
     ev_lds_barrier();
+    stamp(2);
     const float u1 = mp.w1_scale * sx, inv1 = 1.0f / u1;
     f32x16 acc[TM][2];
 #pragma unroll
@@ -4358,7 +4363,7 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
 #pragma unroll
     for (int sl = 0; sl < 16; ++sl) {
         if (sl + 1 < 16) ldB(B[(sl + 1) & 1], sl + 1);
-        if (sl + 3 < 16) ldA(A[(sl + 3) & 3], sl + 3);
+        if (DBG != 1 && sl + 3 < 16) ldA(A[(sl + 3) & 3], sl + 3);
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt)
 #pragma unroll
@@ -4366,6 +4371,9 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A[sl & 3][i][PA[tt]]), __builtin_bit_cast(f16x8, B[sl & 1][PB[tt]][j]), acc[i][j], 0, 0, 0);
+        // (without this fence hipcc sinks the ring's loads behind the MFMAs of the slab they are meant to run under and drains vmcnt to 0
+        // in every slab: the K loop then takes 10.5 us instead of 5, profiles/r03_ln_qkv_h16_stamps.txt)
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -4373,6 +4381,7 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv1;
+    stamp(3);
     // ---- store (the epilogue's first barrier retires the K loop's LDS reads; its slabs lie in the dead X planes)
     {
         f32x16 a2[2][2];
@@ -4382,12 +4391,14 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
             for (int j = 0; j < 2; ++j) a2[i][j] = acc[i][j];
         conv_epilogue_lean<2, 2, 1>(p, a2, smem + wave * (32 * 68), wave * 96, n0, lane);
     }
+    stamp(4);
     {
         f32x16 a1[1][2];
 #pragma unroll
         for (int j = 0; j < 2; ++j) a1[0][j] = acc[2][j];
         conv_epilogue_lean<1, 2, 1>(p, a1, smem + wave * (32 * 68), wave * 96 + 64, n0, lane);
     }
+    stamp(5);
 }
 
 // ---------------------------------------------------------------------------

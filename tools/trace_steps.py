@@ -11,7 +11,7 @@ kt = src if src.endswith(".csv") else glob.glob(src + "/**/*kernel_trace.csv", r
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 420
 piped = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 rows = sorted(csv.DictReader(open(kt)), key=lambda r: int(r["Dispatch_Id"]))
-fam = ("conv_gemm", "conv_split", "conv_h16", "resblock_pair", "ln_mlp", "attn_out")
+fam = ("conv_gemm", "conv_split", "conv_h16", "resblock_pair", "ln_mlp", "ln_qkv", "attn_out")
 conv = [r for r in rows if any(f in r["Kernel_Name"] for f in fam)]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 print(f"{len(conv)} dispatches of the conv family; {n} per pass")

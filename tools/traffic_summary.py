@@ -8,7 +8,7 @@ def load(d, name):
     out = collections.defaultdict(float); n = collections.Counter()
     for r in csv.DictReader(open(cc)):
         if r["Counter_Name"] == name:
-            k = "conv" if ("conv_gemm" in r["Kernel_Name"] or "conv_split" in r["Kernel_Name"] or "conv_h16" in r["Kernel_Name"] or "resblock_pair" in r["Kernel_Name"] or "ln_mlp" in r["Kernel_Name"] or "attn_out" in r["Kernel_Name"]) else "other"
+            k = "conv" if ("conv_gemm" in r["Kernel_Name"] or "conv_split" in r["Kernel_Name"] or "conv_h16" in r["Kernel_Name"] or "resblock_pair" in r["Kernel_Name"] or "ln_mlp" in r["Kernel_Name"] or "ln_qkv" in r["Kernel_Name"] or "attn_out" in r["Kernel_Name"]) else "other"
             out[k] += float(r["Counter_Value"]); n[k] += 1
     return out, n
 f, nf = load(sys.argv[1], "FETCH_SIZE")
