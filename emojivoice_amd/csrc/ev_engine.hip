@@ -629,8 +629,37 @@ int launch_h16_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
     p.sk.lds_word = (int)smem;
     smem += 48;                                         // the wait word + the waves' pre-scan maxima
     static_assert((size_t)BM * BN <= EV_SK_PART_FLOATS, "hand-off slot");
+    static const char* stamp_file = getenv("EV_BAL_STAMPS");         // diagnostic: phase stamps of a few workgroups, once per layer shape
+    static std::vector<long> stamped;
+    const long sig = ((long)p.nrows << 24) ^ ((long)p.Kpad << 12) ^ p.Mpad ^ ((long)p.ntaps << 40);
+    unsigned long long* d = nullptr;
+    if (stamp_file && *stamp_file && stamped.size() < 8 && std::find(stamped.begin(), stamped.end(), sig) == stamped.end()) {
+        stamped.push_back(sig);
+        HIPCHK(h, hipMalloc((void**)&d, (size_t)G * 16 * sizeof(unsigned long long)));
+        HIPCHK(h, hipMemsetAsync(d, 0, (size_t)G * 16 * sizeof(unsigned long long), h->stream));
+        p.stamps = d;
+    }
     if (lean_acc(p)) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 3>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 3>), dim3(G), dim3(256), smem, h->stream, p); }
     else { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 1>), dim3(G), dim3(256), smem, h->stream, p); }
+    if (d) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        std::vector<unsigned long long> st((size_t)G * 16);
+        HIPCHK(h, hipMemcpy(st.data(), d, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        hipFree(d);
+        if (FILE* f = fopen(stamp_file, "a")) {
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int w = 0; w < G; ++w) for (int k = 0; k < 16; ++k) if (st[(size_t)w * 16 + k]) { t0 = std::min(t0, st[(size_t)w * 16 + k]); t1 = std::max(t1, st[(size_t)w * 16 + k]); }
+            fprintf(f, "## conv_h16_bal_kernel rows=%d Kpad=%d Mpad=%d taps=%d: %d workgroups, %ld units (q=%d r=%d), first stamp -> last %.2f us; per workgroup: start offset | us between consecutive stamps (per pass: pre-scan | per chunk: staged, MFMAs | partial stored or contributors added, epilogue | end)\n",
+                    p.nrows, p.Kpad, p.Mpad, p.ntaps, G, U, p.sk.q, p.sk.r, (double)(t1 - t0) / 100.0);
+            for (int w : {0, 1, 2, 3, 100, 101, 255, 256, 511}) {
+                if (w >= G || !st[(size_t)w * 16]) continue;
+                fprintf(f, "  wg %3d: +%.2f |", w, (double)(st[(size_t)w * 16] - t0) / 100.0);
+                for (int k = 1; k < 16 && st[(size_t)w * 16 + k]; ++k) fprintf(f, " %.2f", (double)(st[(size_t)w * 16 + k] - st[(size_t)w * 16 + k - 1]) / 100.0);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
     return 0;
 }
 inline bool split_bal_ok(const ev_handle* h, const ConvLayer& L, const ConvParams& p, long nwg, int wpc) {

@@ -1700,9 +1700,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams
 }
 
 // ---------------------------------------------------------------------------
-// conv_h16_bal_kernel: conv_split_bal_kernel with the fp16 form of conv_h16_kernel.  Every pass over a chunk range pre-scans what it will
-// stage for its activation scale and brings its accumulators back to true units before they are handed over, spilled or stored, so
-// workgroups that share a tile may run different scales.
+// conv_h16_bal_kernel: conv_split_bal_kernel with the fp16 form of conv_h16_kernel.  Every staged chunk carries its own activation scale (from
+// its rows, in registers, before they are split) and every pass brings its accumulators back to true units before they are handed over,
+// spilled or stored, so workgroups that share a tile may run different scales.
 // ---------------------------------------------------------------------------
 template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN>
 __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p) {
@@ -1736,6 +1736,9 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
     constexpr int XG = 4;
     static_assert(XPASS % XG == 0, "staging batches");
     const int xrows = BN + p.halo_lo + p.halo_hi;
+    int nst = 0;                                       // diagnostic (EV_BAL_STAMPS): up to 16 s_memrealtime stamps per workgroup
+    auto stamp = [&]() { if (p.stamps && tid == 0 && nst < 16) p.stamps[16 * g + nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
+    stamp();
 
     while (u < ue) {
         const int t = u / nchunks, c0 = u - t * nchunks;
@@ -1783,30 +1786,12 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
         int gi = g + 1;
         const int tile_end = (t + 1) * nchunks;
         for (;;) {
-            // pre-scan of the chunks this pass stages: their maximum sets the pass's activation scale (conv_h16_kernel)
-            float xs;
-            {
-                float mx = 0.f;
-                for (int ch = cA; ch < cB; ++ch) {
-                    const unsigned soff = evx_chunk_off(p, ch);
-#pragma unroll
-                    for (int q0 = 0; q0 < XPASS; q0 += XG) {
-                        if (q0 * RPS >= xrows) continue;
-                        f32x4 xg[XG];
-#pragma unroll
-                        for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff(q0 + q), soff);
-#pragma unroll
-                        for (int q = 0; q < XG; ++q) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xg[q][0]), fabsf(xg[q][1]))), fmaxf(fabsf(xg[q][2]), fabsf(xg[q][3])));
-                    }
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-                ev_lds_barrier();                          // (the previous pass / segment is done with LDS)
-                if (lane == 0) hred[wave] = mx;
-                ev_lds_barrier();
-                xs = evh_scale_for(fmaxf(fmaxf(hred[0], hred[1]), fmaxf(hred[2], hred[3])));
-            }
-            const float acc_in = p.wh_scale * xs, acc_out = 1.0f / acc_in;
+            // One activation scale per staged CHUNK, taken from the chunk's own rows while they wait in registers (no pre-scan pass: the
+            // launches of the U-Net are one round of workgroups in lockstep, and a pre-scan that re-read every tile — 70-100 MB per
+            // launch, all workgroups at once — took 13-27 us of their 62-90 us: per-workgroup stamps, EV_BAL_STAMPS,
+            // profiles/r03_conv_h16_bal_stamps.txt).  The accumulators run in units of wh_scale * (scale of the chunk in LDS) and are
+            // rescaled by an exact power of two when that changes (ln_mlp_h16_kernel does the same per hidden chunk).
+            float xs = 1.0f;                               // scale of the chunk whose planes are in LDS (none yet: unit 1)
             f32x16 acc[TM][TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
@@ -1816,7 +1801,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
                     f32x4 z = {0.f, 0.f, 0.f, 0.f};
                     bq[q] = z;
                     const int cc = m0 + wm * (TM * 32) + a * 32 + 8 * q + 4 * lh;   // bias preloaded (lean epilogue), by the owner's first pass only
-                    if (p.bias && cA == 0 && cc < p.Cout) bq[q] = *(const f32x4*)(p.bias + cc) * acc_in;
+                    if (p.bias && cA == 0 && cc < p.Cout) bq[q] = *(const f32x4*)(p.bias + cc) * p.wh_scale;
                 }
 #pragma unroll
                 for (int b = 0; b < TN; ++b)
@@ -1829,34 +1814,55 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
             }
             for (int ch = cA; ch < cB; ++ch) {
                 __builtin_amdgcn_s_setprio(3);
-                ev_lds_barrier();                          // the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
                 {
+                    // the chunk's rows into registers (requested before the barrier: the round trip overlaps the other waves' last MFMAs),
+                    // prologue applied, and this thread's maximum over the rows the tile really holds
                     const unsigned soff = evx_chunk_off(p, ch);
+                    f32x4 xg[XPASS];
 #pragma unroll
-                    for (int q0 = 0; q0 < XPASS; q0 += XG) {
-                        if (q0 * RPS >= xrows) continue;
-                        f32x4 xg[XG];
+                    for (int q = 0; q < XPASS; ++q) xg[q] = ev_bload4(rX, xoff(q), soff);
+                    float mx = 0.f;
 #pragma unroll
-                        for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff(q0 + q), soff);
+                    for (int q = 0; q < XPASS; ++q) {
+                        f32x4 v = xg[q];
+                        if (p.pro_lrelu) {
+                            v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+                            v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+                        }
+                        xg[q] = v;
+                        const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
+                        mx = (q * RPS + srow < xrows) ? fmaxf(mx, m4) : mx;
+                    }
 #pragma unroll
-                        for (int q = 0; q < XG; ++q) {
-                            const int r = (q0 + q) * RPS + srow;
-                            f32x4 v = xg[q];
-                            if (p.pro_lrelu) {
-                                v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
-                                v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
-                            }
-                            uint2 q0v, q1v;
-                            evh_split4(v * xs, q0v, q1v);
-                            if (r < xrows) {
-                                char* dst = Xb + r * EVH_RSB + sc4 * 2;
-                                *(uint2*)(dst) = q0v; *(uint2*)(dst + EVX_KC * 2) = q1v;
-                            }
+                    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                    float* hr = hred + 4 * ((ch - cA) & 1);    // (two sets: the set of chunk ch - 2 was read before that chunk's second barrier)
+                    if (lane == 0) hr[wave] = mx;
+                    ev_lds_barrier();                      // maxima published; the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
+                    const float xn = evh_scale_for(fmaxf(fmaxf(hr[0], hr[1]), fmaxf(hr[2], hr[3])));
+                    if (xn != xs) {                        // (workgroup-uniform)
+                        const float f = xn / xs;
+#pragma unroll
+                        for (int a = 0; a < TM; ++a)
+#pragma unroll
+                            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) acc[a][b][r] *= f;
+                        xs = xn;
+                    }
+#pragma unroll
+                    for (int q = 0; q < XPASS; ++q) {
+                        const int r = q * RPS + srow;
+                        uint2 q0v, q1v;
+                        evh_split4(xg[q] * xs, q0v, q1v);
+                        if (r < xrows) {
+                            char* dst = Xb + r * EVH_RSB + sc4 * 2;
+                            *(uint2*)(dst) = q0v; *(uint2*)(dst + EVX_KC * 2) = q1v;
                         }
                     }
                 }
                 ev_lds_barrier();
                 __builtin_amdgcn_s_setprio(0);
+                stamp();                                   // chunk staged
                 const char* brow = bbase + tv_first.y * EVH_RSB;
                 ldB(B0, brow, 0);
                 for (int ti = 0; ti < nact; ++ti) {
@@ -1887,7 +1893,9 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
                     ldAp(A3, nap + 6144u);
                     brow = nbrow;
                 }
+                stamp();                                   // chunk's MFMAs issued
             }
+            const float acc_out = 1.0f / (p.wh_scale * xs);
 #pragma unroll
             for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -1916,6 +1924,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
             if (c0 != 0) {                                 // not the owner: hand the partial tile over (flag raised at the next segment)
                 acc_io((unsigned)g * pslot, 0);
                 pend_pub = true;
+                stamp();                                   // partial stored
                 break;
             }
             bool again = false;
@@ -1939,12 +1948,15 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
                 }
             }
             if (again) continue;
+            stamp();                                       // contributors' partials added
             __builtin_amdgcn_s_setprio(3);
             conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
             __builtin_amdgcn_s_setprio(0);
+            stamp();                                       // epilogue done
             break;
         }
     }
+    stamp();
     if (pend_pub) sk_publish(p.sk, g, tag, tid);
     sk_arrive(p.sk, tag, tid);
 }
