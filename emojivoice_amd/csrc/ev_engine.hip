@@ -639,8 +639,14 @@ int launch_h16_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
         HIPCHK(h, hipMemsetAsync(d, 0, (size_t)G * 16 * sizeof(unsigned long long), h->stream));
         p.stamps = d;
     }
-    if (lean_acc(p)) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 3>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 3>), dim3(G), dim3(256), smem, h->stream, p); }
-    else { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 1>), dim3(G), dim3(256), smem, h->stream, p); }
+    const bool narrow = BN + p.halo_lo + p.halo_hi <= 16 * 9;         // a 3-tap layer: nine staging passes instead of twelve
+    if (lean_acc(p)) {
+        if (narrow) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 3, 9>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 3, 9>), dim3(G), dim3(256), smem, h->stream, p); }
+        else { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 3>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 3>), dim3(G), dim3(256), smem, h->stream, p); }
+    } else {
+        if (narrow) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 1, 9>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 1, 9>), dim3(G), dim3(256), smem, h->stream, p); }
+        else { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 1>), dim3(G), dim3(256), smem, h->stream, p); }
+    }
     if (d) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
         std::vector<unsigned long long> st((size_t)G * 16);

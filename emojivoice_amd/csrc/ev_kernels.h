@@ -1704,7 +1704,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams
 // its rows, in registers, before they are split) and every pass brings its accumulators back to true units before they are handed over,
 // spilled or stored, so workgroups that share a tile may run different scales.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN>
+// XP = staging passes of 16 rows a chunk is read in: 12 covers the widest halo, 9 the 3-tap layers of the U-Net (host-checked: BN + halo <= 16 XP) —
+// twelve registers fewer held beside the accumulators and the weight ring.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN, int XP = (BN + EV_HALO) / 16>
 __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
@@ -1718,7 +1720,10 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
     const int li = lane & 31, lh = lane >> 5;
     const int nchunks = p.Kpad / EVX_KC;
     const int g = blockIdx.x;
-    const unsigned tag = sk_tag(p.sk);
+    // (the epoch is requested here and consumed at its first use — a hand-off, long after — so that its round trip does not stand in front
+    // of the first tile's loads)
+    const unsigned tag_v = p.sk.ctrl ? (unsigned)__hip_atomic_load((ev_gu32*)p.sk.ctrl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    auto get_tag = [&]() -> unsigned { return p.sk.ctrl ? (unsigned)__builtin_amdgcn_readfirstlane((int)tag_v) + 1u : 0u; };
     int u = sk_start(p.sk, g);
     const int ue = sk_start(p.sk, g + 1);
     const __amdgpu_buffer_rsrc_t rPart = ev_rsrc(p.sk.part), rW = ev_rsrc(p.Wh), rX = ev_rsrc(p.X);
@@ -1732,9 +1737,8 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
     const int KG16 = p.Kpad >> 4;
     constexpr int TPR = EVX_KC / 4, RPS = 256 / TPR;
     const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
-    constexpr int XPASS = (BN + EV_HALO) / RPS;
-    constexpr int XG = 4;
-    static_assert(XPASS % XG == 0, "staging batches");
+    static_assert(RPS == 16, "staging rows per pass");
+    constexpr int XPASS = XP;
     const int xrows = BN + p.halo_lo + p.halo_hi;
     int nst = 0;                                       // diagnostic (EV_BAL_STAMPS): up to 16 s_memrealtime stamps per workgroup
     auto stamp = [&]() { if (p.stamps && tid == 0 && nst < 16) p.stamps[16 * g + nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
@@ -1754,7 +1758,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
             else dist = p.S - (n0 % p.S) + p.P;
             if (dist >= BN || n0 + dist >= p.nrows) continue;
         }
-        if (pend_pub) { sk_publish(p.sk, g, tag, tid); pend_pub = false; }
+        if (pend_pub) { sk_publish(p.sk, g, get_tag(), tid); pend_pub = false; }
         const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
         const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
         const int mt32 = (m0 + wm * (TM * 32)) >> 5;
@@ -1932,7 +1936,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
                 int n = 0;
                 while (n < 64 && gi + n < (int)gridDim.x && sk_start(p.sk, gi + n) < tile_end) ++n;
                 if (n == 0) break;
-                const int ready = sk_wait_many(p.sk, gi, n, tag, tid, skw);
+                const int ready = sk_wait_many(p.sk, gi, n, get_tag(), tid, skw);
                 for (int k = 0; k < ready; ++k) acc_io((unsigned)(gi + k) * pslot, 1);
                 gi += ready;
                 if (ready < n) {                           // gi is not there in time: spill the running sum, compute its share here
@@ -1957,8 +1961,8 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
         }
     }
     stamp();
-    if (pend_pub) sk_publish(p.sk, g, tag, tid);
-    sk_arrive(p.sk, tag, tid);
+    if (pend_pub) sk_publish(p.sk, g, get_tag(), tid);
+    sk_arrive(p.sk, get_tag(), tid);
 }
 
 // (A loader-wave build of this kernel — two extra waves per workgroup that only stage X tiles, so that the MFMA waves
