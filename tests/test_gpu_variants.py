@@ -92,7 +92,8 @@ def test_batch64_balanced_builds(tmp_path):
     nowait = _run(tmp_path, "b64_nowait", {"EV_SK_SPIN": "0"}, "b64")
     assert torch.equal(nowait["mel"], ref["mel"]) and torch.equal(nowait["wav"], ref["wav"])
     # (run-to-run equality of the default build is covered in-process by tests/test_gpu_ops.py; every switch here costs a batch-64 child)
-    for i, extra in enumerate([{"EV_NO_SK_BALANCE": "1"}, {"EV_CONV_BALANCE_W": "1", "EV_BAL5": "64"}, {"EV_FUSE_ATTN": "0", "EV_SK_WGS": "3"}, {"EV_SPLIT": "0"}, {"EV_SPLIT": "6"}]):
+    for i, extra in enumerate([{"EV_NO_SK_BALANCE": "1"}, {"EV_CONV_BALANCE_W": "1", "EV_BAL5": "64"}, {"EV_FUSE_ATTN": "0", "EV_SK_WGS": "3"}, {"EV_SPLIT": "0"}, {"EV_SPLIT": "6"},
+                               {"EV_NO_QKV_H16": "1"}]):     # (LayerNorm + QKV back on the fp32 MFMA build)
         got = _run(tmp_path, f"b64_v{i}", extra, "b64")
         dmel = float((got["mel"] - ref["mel"]).abs().max())
         dwav = float((got["wav"] - ref["wav"]).abs().max())
