@@ -154,6 +154,7 @@ struct ev_handle {
     int split_terms = 16;           // arithmetic of the deep layers' products (ev_set_arithmetic; EV_SPLIT presets it): 16 = shipped: two block-scaled
                                     // fp16 pieces per operand, three products (fp32-grade); 6 = three bf16 pieces, six products (fp32-grade, no
                                     // range handling needed); 0 = fp32 MFMA everywhere; 3 = opt-in fast bf16 setting (not fp32-grade); 9 = A/B
+    int n_fp32_only_layers = 0;     // layers whose weights are not the exact sum of three bf16 pieces (tiny or non-finite): they keep the fp32 MFMA build
     int last_cfg = -1;              // build the last launch_conv / launch_pair took (ev_dbg_last_cfg: tests assert that a shape ran on the build they mean)
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
     bool sk_spread = false;         // EV_SK_SPREAD=1: launches of fewer row tiles than CUs (small batches) spread their units over up to 2 x CUs workgroups
@@ -252,7 +253,11 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
         std::vector<unsigned short> Wx(Wh.size() * 3);
         auto bits = [](float f) { unsigned u; memcpy(&u, &f, 4); return u; };
         auto fl = [](unsigned u) { float f; memcpy(&f, &u, 4); return f; };
-        for (int tap = 0; tap < L.ntaps; ++tap)
+        // A weight whose residuals reach the subnormal range (|w| below ~1e-33) or that is not finite is NOT the exact sum of three truncated
+        // bf16 pieces.  Such a checkpoint still loads (the reference loads it): the layer keeps no piece planes (Wx stays null), every gate of
+        // the 16-bit-pipe builds tests Wx, so the layer runs on the exact fp32 MFMA build whatever the arithmetic setting.
+        bool exact = true;
+        for (int tap = 0; tap < L.ntaps && exact; ++tap)
             for (int mt = 0; mt < MT32; ++mt)
                 for (int kg = 0; kg < KG16; ++kg)
                     for (int lane = 0; lane < 64; ++lane)
@@ -263,11 +268,12 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                             const float r1 = w - fl(p0);
                             const unsigned p1 = bits(r1) & 0xffff0000u;
                             const unsigned p2 = bits(r1 - fl(p1)) & 0xffff0000u;
-                            if (fl(p0) + fl(p1) + fl(p2) != w && w == w) return fail(h, "weight %g is not the exact sum of three bf16 pieces (non-finite or subnormal?)", (double)w);
+                            if (!(fl(p0) + fl(p1) + fl(p2) == w)) exact = false;
                             const size_t base = ((((size_t)tap * MT32 + mt) * KG16 + kg) * 3) * 512 + (size_t)lane * 8 + e;
                             Wx[base] = (unsigned short)(p0 >> 16); Wx[base + 512] = (unsigned short)(p1 >> 16); Wx[base + 1024] = (unsigned short)(p2 >> 16);
                         }
-        if (dev_upload(h, Wx, &L.Wx)) return 1;
+        if (exact) { if (dev_upload(h, Wx, &L.Wx)) return 1; }
+        else ++h->n_fp32_only_layers;
     }
     if (bias) { if (dev_upload(h, *bias, &L.bias)) return 1; }
     // per-tile compact lists of non-zero taps (polyphase transposed convs have all-zero (phase, tap) slabs)
@@ -564,6 +570,7 @@ constexpr int EV_SK_PART_FLOATS = 16384;   // largest partial accumulator tile h
 // Hand-off area of the balanced launches: allocated once per handle (never inside a stream capture: ev_load_estimator calls this)
 int ensure_sk(ev_handle* h) {
     if (h->sk_ctrl) return 0;
+    ++h->n_allocs;             // (every loader and ev_reserve call this, so a hot call never gets here; if one ever does, ev_alloc_count shows it)
     const size_t words = 16 + EV_SK_MAXWG;
     HIPCHK(h, hipMalloc((void**)&h->sk_ctrl, words * sizeof(unsigned)));
     HIPCHK(h, hipMemset(h->sk_ctrl, 0, words * sizeof(unsigned)));
@@ -627,7 +634,7 @@ int launch_h16_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
     constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4) * sizeof(float);
     size_t smem = xs > es ? xs : es;
     p.sk.lds_word = (int)smem;
-    smem += 48;                                         // the wait word + the waves' pre-scan maxima
+    smem += 64;                                         // the wait word + three sets of the waves' maxima
     static_assert((size_t)BM * BN <= EV_SK_PART_FLOATS, "hand-off slot");
     static const char* stamp_file = getenv("EV_BAL_STAMPS");         // diagnostic: phase stamps of a few workgroups, once per layer shape
     static std::vector<long> stamped;
@@ -969,7 +976,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         const int NT = C == 32 ? 256 : C == 64 ? 128 : 64, RSB = 4 * C + 16;
         if (C != 32 && C != 64 && C != 128) return fail(h, "launch_pair: C must be 32, 64 or 128");
         pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
-        const size_t smem = std::max((size_t)(NT + EV_HALO) * RSB + 32, (size_t)4 * 32 * 36 * sizeof(float));
+        const size_t smem = std::max((size_t)(NT + EV_HALO) * RSB + 64, (size_t)4 * 32 * 36 * sizeof(float));   // (+ 16 floats: the waves' maxima)
         const dim3 grid(p.ntiles);
 #define EV_PAIR_H16(WM, WN) do { \
             if (lean == 1) { ensure_dyn_smem<resblock_pair_h16_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_h16_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, pp); } \
@@ -1112,7 +1119,7 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
             mp.sk.q = (int)(U / grid); mp.sk.r = (int)(U % grid); mp.sk.spin_limit = h->sk_spin;
             mp.sk.ctrl = h->sk_ctrl; mp.sk.flags = h->sk_ctrl + 16; mp.sk.part = h->sk_part; mp.sk.part_floats = EV_SK_PART_FLOATS;
             if (L1.Mpad > 1024) return fail(h, "launch_mlp: hidden width %d > 1024 (LDS table of the SnakeBeta vectors)", L1.Mpad);
-            const size_t smem = h16 ? (size_t)64 * (4 * 256 + 16) + (size_t)64 * (4 * 128 + 16) + 16 + (size_t)2 * L1.Mpad * sizeof(float) + 32
+            const size_t smem = h16 ? (size_t)64 * (4 * 256 + 16) + (size_t)64 * (4 * 128 + 16) + 16 + (size_t)2 * L1.Mpad * sizeof(float) + 64
                                     : (size_t)64 * (6 * 256 + 16) + (size_t)64 * (6 * 128 + 16) + 16 + (size_t)2 * L1.Mpad * sizeof(float);
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->prof) {
@@ -1167,7 +1174,7 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
         const int nt64 = (g.nrows + 63) / 64;
         if (mode == 1 && h->split_terms == 16 && !no_qkv_h16 && L1.Wh && L1.Mpad == 384 && !R && !rowmask && h->ncu > 0 && nt64 >= h->ncu) {
             mp.W1h = L1.Wh; mp.w1_scale = L1.wh_scale; mp.ntiles = nt64;
-            const size_t smem = (size_t)64 * (4 * 256 + 16) + 16;
+            const size_t smem = (size_t)64 * (4 * 256 + 16) + 32;   // (+ 8 floats: the waves' maxima and their finite-only repeat)
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->prof) {
                 if (h->ev_used + 2 > h->ev_pool.size()) {
@@ -2105,6 +2112,7 @@ int ev_load_vocoder(ev_handle* h, const float* blob, const ev_tensor_index* inde
                 REQ(pack_conv(h, v.c2[i * 3 + j][mm], *w2, b2, 1));
             }
     }
+    REQ(ensure_sk(h));     // the balanced builds' hand-off area: a mid-size ev_hifigan call (e.g. 8 x 516 frames) takes them — never allocate on the request path
     v.loaded = true;
     return 0;
 }
@@ -2310,6 +2318,7 @@ int ev_reserve(ev_handle* h, int B, int Tx_max, int Tp_max, int T_voc_max, void*
     HIPCHK(h, hipSetDevice(h->device));
     if (B <= 0 || Tx_max < 0 || Tp_max < 0 || T_voc_max < 0 || (Tp_max & 3)) return fail(h, "ev_reserve: bad shape B=%d Tx=%d Tp=%d (multiple of 4) T_voc=%d", B, Tx_max, Tp_max, T_voc_max);
     h->stream = (hipStream_t)stream;
+    if (ensure_sk(h)) return 1;                       // (normally there since the loaders; a handle reserved before any load gets it here)
     if (Tp_max > 0 || T_voc_max > 0) {
         // the plan is monotonic in every argument except for the three-stream scratch of small vocoder calls: take the larger
         size_t need = plan_all(h, nullptr, B, Tp_max, T_voc_max, nullptr, nullptr);

@@ -318,6 +318,10 @@ template <int TM, int TN, int MODE = 1, class Hook = EvNoHook>
 __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane,
                                                    int win_lo = -0x7fffffff, int win_hi = 0x7fffffff, Hook after_issue = Hook()) {
     constexpr int EC = TM * 32, ELD = EC + 4, C4 = EC / 4, RPP = 64 / C4, NP = 32 / RPP;
+    // Everything per-lane below derives from `lane`.  Left visible, hipcc computes these offsets — loop invariants of the callers' tile /
+    // chunk loops — at the top of the kernel and keeps them in registers through the K loop; in the persistent builds that cost 30-60
+    // registers and put conv_h16_bal_kernel / ln_mlp_h16_kernel into scratch (round 3).  The empty asm makes them start HERE.
+    asm volatile("" : "+v"(lane));
     const int li = lane & 31, lh = lane >> 5;
     const int er = lane / C4, ec = (lane % C4) * 4;
     const int co = mw0 + ec;
@@ -462,9 +466,19 @@ __device__ __forceinline__ f32x4 ev_bload4_sc1(__amdgpu_buffer_rsrc_t r, unsigne
 __device__ __forceinline__ void ev_bstore4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff_bytes, 0, 16);       // write-through
 }
+// ... with the wave-uniform part of the address in the scalar offset: the per-lane part stays ONE register for every slot of a partial tile
+// (as `base + lane part + k KiB` in the vector offset hipcc hoisted sixteen loop-invariant per-lane addresses out of the unit loop and
+// spilled them to scratch — the conv_h16_bal_kernel / ln_mlp_h16_kernel spills of round 3)
+__device__ __forceinline__ f32x4 ev_bload4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff_bytes, (int)soff_bytes, 16));
+}
+__device__ __forceinline__ void ev_bstore4_sc1(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), r, (int)voff_bytes, (int)soff_bytes, 16);
+}
 // after every wave's payload stores: drain, meet, ONE lane raises the flag
 __device__ __forceinline__ void sk_publish(const SkCtl& c, int g, unsigned tag, int tid) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    asm volatile("" : "+s"(tag));                      // (the tag lives in a scalar register; its vector copy for the store is made here, not kept — or spilled — across the unit loop)
     if (tid == 0) __hip_atomic_store((ev_gu32*)(c.flags + g), tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // true when workgroup gi's partial of this launch is readable by every wave of the caller (all threads must call; `word` = one LDS int)
@@ -1199,12 +1213,12 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_bal_kernel(const ConvParams 
                     for (int b = 0; b < TN; ++b)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const unsigned off = base + pelem + (unsigned)((a * TN + b) * 4 + q) * 1024u;
+                            const unsigned soff = base + (unsigned)((a * TN + b) * 4 + q) * 1024u;     // (wave-uniform: scalar offset)
                             if (mode == 0) {
                                 const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-                                ev_bstore4_sc1(rPart, off, v);
+                                ev_bstore4_sc1(rPart, pelem, soff, v);
                             } else {
-                                const f32x4 v = ev_bload4_sc1(rPart, off);
+                                const f32x4 v = ev_bload4_sc1(rPart, pelem, soff);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[a][b][4 * q + e] += v[e];
                             }
@@ -1272,13 +1286,30 @@ __device__ __forceinline__ void evh_split4(const f32x4 v, uint2& q0, uint2& q1) 
     q0.x = __builtin_bit_cast(unsigned, a); q0.y = __builtin_bit_cast(unsigned, b);
     q1.x = __builtin_bit_cast(unsigned, c); q1.y = __builtin_bit_cast(unsigned, d);
 }
-// power of two s with max * s in [8192, 16384)  (max = 0 or not finite: 1)
+// power of two s with max * s in [8192, 16384), clamped to [2^-40, 2^40]  (max = 0 or not finite: 1).
+// The clamp bounds everything derived from a scale: the product with a weight scale (also within 2^+-40) stays within 2^+-80, and the factor
+// xn / xs by which conv_h16_bal_kernel / ln_mlp_h16_kernel move their running sums (bounded by 2^40 in their own unit) from one chunk's scale
+// to the next is at most 2^80: no step can overflow fp32.  A tile whose maximum is below 2^-27 is ~0 beside the bias; one whose finite maximum
+// exceeds 2^55 (3.6e16) leaves fp16's range and comes out as Inf where the fp32 builds would still be finite — documented in DESIGN 3.
 __device__ __forceinline__ float evh_scale_for(float mx) {
     const int ex = (int)((__float_as_uint(mx) >> 23) & 255u);          // biased exponent of max
     if (ex == 0 || ex == 255) return 1.f;
-    const int e2 = 267 - ex;                                            // biased exponent of 2^(13 - floor(log2 max))
-    return __uint_as_float((unsigned)(e2 > 167 ? 167 : e2) << 23);      // (at most 2^40: a tile whose maximum is below 2^-27 is ~0 beside the bias, and the
-                                                                        // product of the two scales must stay far from the fp32 range)
+    int e2 = 267 - ex;                                                  // biased exponent of 2^(13 - floor(log2 max))
+    e2 = e2 > 167 ? 167 : (e2 < 87 ? 87 : e2);
+    return __uint_as_float((unsigned)e2 << 23);
+}
+// A tile maximum that is not finite (an Inf among the staged values; NaNs never reach a maximum: v_max ignores them) must not set the
+// tile's scale: with scale 1 every finite value above 65504 of the SAME tile would overflow too and the small ones would lose their second
+// piece — rows of another utterance that merely share the tile with the bad one.  The kernels therefore repeat their search over the FINITE
+// values only (workgroup-uniform slow path, never taken on clean data); the non-finite elements themselves become fp16 Inf / NaN and spoil
+// exactly the outputs whose taps touch them, as in the fp32 builds.
+__device__ __forceinline__ bool evh_is_finite(float m) { return (__float_as_uint(m) & 0x7f800000u) != 0x7f800000u; }
+__device__ __forceinline__ float evh_absmax4(const f32x4 v) { return fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))); }
+__device__ __forceinline__ float evh_absmax4_finite(const f32x4 v) {
+    float m = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float a = fabsf(v[e]); m = fmaxf(m, evh_is_finite(a) ? a : 0.f); }
+    return m;
 }
 template <int TM, int TN>
 __device__ __forceinline__ void evh_mma(f32x16 (&acc)[TM][TN], const f32x4 (&a)[2][TM], const f32x4 (&b)[2][TN]) {
@@ -1368,24 +1399,33 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
     // ---- pre-scan: max |x| (after the prologue: |lrelu(x)| <= |x|, so the raw maximum bounds it) over everything this tile stages
     float xs;
     {
-        float mx = 0.f;
-        for (int ch = 0; ch < ((p.dbg & 2048) ? 0 : nchunks); ++ch) {      // (dbg 2048: tools/conv_bench.py ablation — no pre-scan, a fixed scale of 1024)
-            const unsigned soff = evx_chunk_off(p, ch);
+        auto scan = [&](auto finite_only) -> float {
+            constexpr bool FIN = decltype(finite_only)::value;
+            float mx = 0.f;
+            for (int ch = 0; ch < ((p.dbg & 2048) ? 0 : nchunks); ++ch) {      // (dbg 2048: tools/conv_bench.py ablation — no pre-scan, a fixed scale of 1024)
+                const unsigned soff = evx_chunk_off(p, ch);
 #pragma unroll
-            for (int q0 = 0; q0 < XPASS; q0 += XG) {
-                if (q0 * RPS >= xrows) continue;
-                f32x4 xg[XG];
+                for (int q0 = 0; q0 < XPASS; q0 += XG) {
+                    if (q0 * RPS >= xrows) continue;
+                    f32x4 xg[XG];
 #pragma unroll
-                for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff[q0 + q], soff);
+                    for (int q = 0; q < XG; ++q) xg[q] = ev_bload4(rX, xoff[q0 + q], soff);
 #pragma unroll
-                for (int q = 0; q < XG; ++q) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xg[q][0]), fabsf(xg[q][1]))), fmaxf(fabsf(xg[q][2]), fabsf(xg[q][3])));
+                    for (int q = 0; q < XG; ++q) mx = fmaxf(mx, FIN ? evh_absmax4_finite(xg[q]) : evh_absmax4(xg[q]));
+                }
             }
-        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        if (lane == 0) red[wave] = mx;
-        ev_lds_barrier();
-        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if (lane == 0) red[wave] = mx;
+            ev_lds_barrier();
+            mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            return mx;
+        };
+        float mx = scan(std::false_type{});
+        if (!evh_is_finite(mx)) {                           // an Inf in the tile (workgroup-uniform): the finite maximum sets the scale
+            ev_lds_barrier();                               // (every wave has read red[])
+            mx = scan(std::true_type{});
+        }
         xs = (p.dbg & 2048) ? 1024.f : evh_scale_for(mx);
     }
     const float acc_in = p.wh_scale * xs;              // bias in accumulator units
@@ -1553,7 +1593,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams
         const char* bbase = Xb + (wn * (TN * 32) + li + p.halo_lo) * EVX_RSB + 16 * lh;
         const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
         const int2 tv_first = ev_tap_at(tlv, 0);
-        const int gr0 = n0 - p.halo_lo + srow;             // first staging row of this thread (rows outside the tensor / the tile read pad row 0)
+        int gr0 = n0 - p.halo_lo + srow;                   // first staging row of this thread (rows outside the tensor / the tile read pad row 0)
         auto xoff = [&](int q) -> unsigned {
             const int gr = gr0 + q * RPS;
             return ((q * RPS < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
@@ -1588,6 +1628,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams
                 ev_lds_barrier();                          // the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
                 {
                     const unsigned soff = evx_chunk_off(p, ch);
+                    asm volatile("" : "+v"(gr0));          // (row offsets recomputed per chunk, not kept — and spilled — as loop invariants: conv_h16_bal_kernel)
 #pragma unroll
                     for (int q0 = 0; q0 < XPASS; q0 += XG) {
                         if (q0 * RPS >= xrows) continue;
@@ -1651,12 +1692,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams
                     for (int b = 0; b < TN; ++b)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const unsigned off = base + pelem + (unsigned)((a * TN + b) * 4 + q) * 1024u;
+                            const unsigned soff = base + (unsigned)((a * TN + b) * 4 + q) * 1024u;     // (wave-uniform: scalar offset)
                             if (mode == 0) {
                                 const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-                                ev_bstore4_sc1(rPart, off, v);
+                                ev_bstore4_sc1(rPart, pelem, soff, v);
                             } else {
-                                const f32x4 v = ev_bload4_sc1(rPart, off);
+                                const f32x4 v = ev_bload4_sc1(rPart, pelem, soff);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[a][b][4 * q + e] += v[e];
                             }
@@ -1706,7 +1747,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams
 // ---------------------------------------------------------------------------
 // XP = staging passes of 16 rows a chunk is read in: 12 covers the widest halo, 9 the 3-tap layers of the U-Net (host-checked: BN + halo <= 16 XP) —
 // twelve registers fewer held beside the accumulators and the weight ring.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN, int XP = (BN + EV_HALO) / 16>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN, int XP = (BN + EV_HALO) / 16, int XK = (XP > 9 ? 8 : XP)>
 __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
@@ -1780,7 +1821,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
         const char* bbase = Xb + (wn * (TN * 32) + li + p.halo_lo) * EVH_RSB + 16 * lh;
         const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
         const int2 tv_first = ev_tap_at(tlv, 0);
-        const int gr0 = n0 - p.halo_lo + srow;             // first staging row of this thread (rows outside the tensor / the tile read pad row 0)
+        int gr0 = n0 - p.halo_lo + srow;                   // first staging row of this thread (rows outside the tensor / the tile read pad row 0)
         auto xoff = [&](int q) -> unsigned {
             const int gr = gr0 + q * RPS;
             return ((q * RPS < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u;
@@ -1822,27 +1863,61 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
                     // the chunk's rows into registers (requested before the barrier: the round trip overlaps the other waves' last MFMAs),
                     // prologue applied, and this thread's maximum over the rows the tile really holds
                     const unsigned soff = evx_chunk_off(p, ch);
-                    f32x4 xg[XPASS];
-#pragma unroll
-                    for (int q = 0; q < XPASS; ++q) xg[q] = ev_bload4(rX, xoff(q), soff);
-                    float mx = 0.f;
-#pragma unroll
-                    for (int q = 0; q < XPASS; ++q) {
-                        f32x4 v = xg[q];
+                    // XK of the XPASS staging passes stay in registers from the maximum search to the split; the passes beyond (wide-halo
+                    // layers only: XPASS = 12) are read TWICE — once for the maximum, once more (L2-hot, 16 KB per workgroup) for the split —
+                    // which keeps the build at 36 staging registers instead of 48 and out of scratch.
+                    f32x4 xg[XK];
+                    // (the row offsets are recomputed per chunk — four vector instructions per pass: as loop invariants hipcc kept all of them,
+                    // range tests included, in registers across the MFMA phase and spilled them to scratch; the empty asm hides the invariance)
+                    asm volatile("" : "+v"(gr0));
+                    auto pro = [&](f32x4 v) -> f32x4 {
                         if (p.pro_lrelu) {
                             v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
                             v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
                         }
+                        return v;
+                    };
+                    float mx = 0.f, mxf = 0.f;             // maximum / maximum over the finite values of the re-read passes
+                    if constexpr (XPASS > XK) {
+                        f32x4 xt[XPASS - XK];
+#pragma unroll
+                        for (int q = XK; q < XPASS; ++q) xt[q - XK] = ev_bload4(rX, xoff(q), soff);
+#pragma unroll
+                        for (int q = 0; q < XK; ++q) xg[q] = ev_bload4(rX, xoff(q), soff);
+#pragma unroll
+                        for (int q = XK; q < XPASS; ++q) {
+                            const f32x4 v = pro(xt[q - XK]);
+                            const bool in = q * RPS + srow < xrows;
+                            mx = in ? fmaxf(mx, evh_absmax4(v)) : mx;
+                            mxf = in ? fmaxf(mxf, evh_absmax4_finite(v)) : mxf;
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < XK; ++q) xg[q] = ev_bload4(rX, xoff(q), soff);
+                    }
+#pragma unroll
+                    for (int q = 0; q < XK; ++q) {
+                        const f32x4 v = pro(xg[q]);
                         xg[q] = v;
-                        const float m4 = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3])));
-                        mx = (q * RPS + srow < xrows) ? fmaxf(mx, m4) : mx;
+                        mx = (q * RPS + srow < xrows) ? fmaxf(mx, evh_absmax4(v)) : mx;
                     }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
                     float* hr = hred + 4 * ((ch - cA) & 1);    // (two sets: the set of chunk ch - 2 was read before that chunk's second barrier)
                     if (lane == 0) hr[wave] = mx;
                     ev_lds_barrier();                      // maxima published; the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
-                    const float xn = evh_scale_for(fmaxf(fmaxf(hr[0], hr[1]), fmaxf(hr[2], hr[3])));
+                    float cmx = fmaxf(fmaxf(hr[0], hr[1]), fmaxf(hr[2], hr[3]));
+                    if (!evh_is_finite(cmx)) {             // an Inf among the chunk's rows (workgroup-uniform, never on clean data): the finite maximum sets the scale
+                        mx = mxf;
+#pragma unroll
+                        for (int q = 0; q < XK; ++q) mx = (q * RPS + srow < xrows) ? fmaxf(mx, evh_absmax4_finite(xg[q])) : mx;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                        if (lane == 0) hred[8 + wave] = mx;    // (a third set: only this path writes it, always behind the barrier above)
+                        ev_lds_barrier();
+                        cmx = fmaxf(fmaxf(hred[8], hred[9]), fmaxf(hred[10], hred[11]));
+                    }
+                    const float xn = evh_scale_for(cmx);
                     if (xn != xs) {                        // (workgroup-uniform)
                         const float f = xn / xs;
 #pragma unroll
@@ -1853,15 +1928,26 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
                                 for (int r = 0; r < 16; ++r) acc[a][b][r] *= f;
                         xs = xn;
                     }
-#pragma unroll
-                    for (int q = 0; q < XPASS; ++q) {
+                    auto put = [&](int q, const f32x4 v) {
                         const int r = q * RPS + srow;
                         uint2 q0v, q1v;
-                        evh_split4(xg[q] * xs, q0v, q1v);
+                        evh_split4(v * xs, q0v, q1v);
                         if (r < xrows) {
                             char* dst = Xb + r * EVH_RSB + sc4 * 2;
                             *(uint2*)(dst) = q0v; *(uint2*)(dst + EVX_KC * 2) = q1v;
                         }
+                    };
+                    if constexpr (XPASS > XK) {            // second read of the passes that were not kept
+                        f32x4 xt[XPASS - XK];
+#pragma unroll
+                        for (int q = XK; q < XPASS; ++q) xt[q - XK] = ev_bload4(rX, xoff(q), soff);
+#pragma unroll
+                        for (int q = 0; q < XK; ++q) put(q, xg[q]);
+#pragma unroll
+                        for (int q = XK; q < XPASS; ++q) put(q, pro(xt[q - XK]));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < XK; ++q) put(q, xg[q]);
                     }
                 }
                 ev_lds_barrier();
@@ -1913,12 +1999,12 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
                     for (int b = 0; b < TN; ++b)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const unsigned off = base + pelem + (unsigned)((a * TN + b) * 4 + q) * 1024u;
+                            const unsigned soff = base + (unsigned)((a * TN + b) * 4 + q) * 1024u;     // (wave-uniform: scalar offset)
                             if (mode == 0) {
                                 const f32x4 v = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
-                                ev_bstore4_sc1(rPart, off, v);
+                                ev_bstore4_sc1(rPart, pelem, soff, v);
                             } else {
-                                const f32x4 v = ev_bload4_sc1(rPart, off);
+                                const f32x4 v = ev_bload4_sc1(rPart, pelem, soff);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc[a][b][4 * q + e] += v[e];
                             }
@@ -2100,6 +2186,8 @@ __global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvPa
             const int adv_r = NTHR / f4row, adv_c = NTHR % f4row;
             const int r0 = tid / f4row, cc0 = tid - r0 * f4row;
             int r = r0, cc = cc0;
+            asm volatile("" : "+v"(r));                   // (the per-pass row offsets are invariants of the round loop: visible, hipcc keeps their products in
+                                                          // registers across the MFMA phase — four of them went to scratch at the 128-register cap of this build)
 #pragma unroll
             for (int q = 0; q < MAXPASS; ++q) {
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -2120,6 +2208,7 @@ __global__ __launch_bounds__(64 * TW * KS) void conv_gemm_sk_kernel(const ConvPa
                 if (set == 1) p.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
             }
             r = r0; cc = cc0;
+            asm volatile("" : "+v"(r));                   // (as above: the LDS write addresses)
 #pragma unroll
             for (int q = 0; q < MAXPASS; ++q) {
                 if (q * NTHR < nf4 && r < xrows) {
@@ -2775,7 +2864,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16_kernel(const PairPar
     const ConvParams& p = pp.c2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* Xb = (char*)smem;                             // phase 1: [NT + 2 h1][RSB];  phase 2 (aliased): y1 [NT + 2 h2][RSB]
-    float* red = smem + ((NT + EV_HALO) * RSB) / 4;     // 8 floats behind the tiles: the waves' maxima (x: 0..3, y1: 4..7)
+    float* red = smem + ((NT + EV_HALO) * RSB) / 4;     // 16 floats behind the tiles: the waves' maxima (x: 0..3, y1: 4..7; their finite-only repeats: 8..11, 12..15)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -2881,8 +2970,15 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16_kernel(const PairPar
             xg[q] = ev_bload4(rX, ((r < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u, 0);   // (row 0 is a zero pad row)
         }
 #pragma unroll
-        for (int q = 0; q < XPASS; ++q) mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xg[q][0]), fabsf(xg[q][1]))), fmaxf(fabsf(xg[q][2]), fabsf(xg[q][3])));
-        sx = evh_scale_for(wg_max(mx, 0));              // (|lrelu(x)| <= |x|)
+        for (int q = 0; q < XPASS; ++q) mx = fmaxf(mx, evh_absmax4(xg[q]));
+        float tmx = wg_max(mx, 0);                      // (|lrelu(x)| <= |x|)
+        if (!evh_is_finite(tmx)) {                      // an Inf in the tile (workgroup-uniform): the finite maximum sets the scale
+            mx = 0.f;
+#pragma unroll
+            for (int q = 0; q < XPASS; ++q) mx = fmaxf(mx, evh_absmax4_finite(xg[q]));
+            tmx = wg_max(mx, 8);
+        }
+        sx = evh_scale_for(tmx);
 #pragma unroll
         for (int q = 0; q < XPASS; ++q) {
             const int r = q * RPS + srow;
@@ -2921,7 +3017,16 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16_kernel(const PairPar
                 my = fmaxf(my, fabsf(v));
             }
         }
-        sy = evh_scale_for(wg_max(my, 4));              // (the barrier inside: every wave is done reading the X tile)
+        float tmy = wg_max(my, 4);                      // (the barrier inside: every wave is done reading the X tile)
+        if (!evh_is_finite(tmy)) {
+            my = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r16 = 0; r16 < 16; ++r16) { const float a = fabsf(acc[0][j][r16]); my = fmaxf(my, evh_is_finite(a) ? a : 0.f); }
+            tmy = wg_max(my, 12);
+        }
+        sy = evh_scale_for(tmy);
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int r = wn * (TN * 32) + j * 32 + li;
@@ -3851,12 +3956,12 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_split_kernel(const MlpParams mp
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const unsigned off = base + pelem + (unsigned)((a * 2 + j) * 4 + q) * 1024u;
+                            const unsigned soff = base + (unsigned)((a * 2 + j) * 4 + q) * 1024u;      // (wave-uniform: scalar offset)
                             if (mode == 0) {
                                 const f32x4 v = {acc2[a][j][4 * q], acc2[a][j][4 * q + 1], acc2[a][j][4 * q + 2], acc2[a][j][4 * q + 3]};
-                                ev_bstore4_sc1(rPart, off, v);
+                                ev_bstore4_sc1(rPart, pelem, soff, v);
                             } else {
-                                const f32x4 v = ev_bload4_sc1(rPart, off);
+                                const f32x4 v = ev_bload4_sc1(rPart, pelem, soff);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc2[a][j][4 * q + e] += v[e];
                             }
@@ -3919,7 +4024,7 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
     char* Hb = Xb + NT * XRS;                           // [NT][HRS]: SnakeBeta(hidden chunk) times the chunk scale as two fp16 planes
     int* skw = (int*)(Hb + NT * HRS);
     float* Sv = (float*)(Hb + NT * HRS + 16);          // SnakeBeta vectors over the hidden width: [alpha (M1) | 1 / beta (M1)], M1 <= 1024
-    float* red = Sv + 2 * mp.M1;                       // the waves' maxima: [0..3] of the normalised rows, [4..7] of a hidden chunk
+    float* red = Sv + 2 * mp.M1;                       // the waves' maxima: [0..3] of the normalised rows, [4..7] of a hidden chunk; [8..11], [12..15]: their finite-only repeats
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5;
@@ -3999,13 +4104,24 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 xv[r] = ev_ln256_row(xv[r], gm, be, mp.ln_eps);
-                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(xv[r][0]), fabsf(xv[r][1]))), fmaxf(fabsf(xv[r][2]), fabsf(xv[r][3])));
+                mx = fmaxf(mx, evh_absmax4(xv[r]));
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
             if (lane == 0) red[wave] = mx;
             ev_lds_barrier();
-            sx = evh_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));   // the tile's activation scale (conv_h16_kernel)
+            float tmx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            if (!evh_is_finite(tmx)) {                  // an Inf among the normalised rows (workgroup-uniform): the finite maximum sets the scale
+                mx = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, evh_absmax4_finite(xv[r]));
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+                if (lane == 0) red[8 + wave] = mx;
+                ev_lds_barrier();
+                tmx = fmaxf(fmaxf(red[8], red[9]), fmaxf(red[10], red[11]));
+            }
+            sx = evh_scale_for(tmx);                    // the tile's activation scale (conv_h16_kernel)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 uint2 q0v, q1v;
@@ -4063,6 +4179,7 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
                         acc2[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a1[PA[tt]]), __builtin_bit_cast(f16x8, b[PB[tt]][j]), acc2[1][j], 0, 0, 0);
                     }
             };
+            __builtin_assume(cA < cB);                 // (a pass always holds at least one chunk: no zero-trip path for the register allocator to keep the ring alive across)
             for (int hc = cA; hc <= cB; ++hc) {
                 const bool p1 = hc < cB, p2 = hc > cA;             // phase 1 of chunk hc / phase 2 of chunk hc - 1 in this iteration
                 const int ht = (p1 ? hc : cA) * 4 + wave;          // (past the last chunk: harmless re-reads)
@@ -4199,7 +4316,18 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
                     if (lane == 0) red[4 + wave] = hmax;
                     hmax = 0.f;
                     ev_lds_barrier();        // every wave is done reading the previous chunk's planes (its phase 2); the waves' maxima are published
-                    sh_lds = evh_scale_for(fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7])));   // this chunk's scale
+                    float hm = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+                    if (!evh_is_finite(hm)) {           // (workgroup-uniform slow path, see evh_is_finite)
+                        float m2 = 0.f;
+#pragma unroll
+                        for (int jq = 0; jq < 8; ++jq) m2 = fmaxf(m2, evh_absmax4_finite(hvs[jq]));
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) m2 = fmaxf(m2, __shfl_xor(m2, o, 64));
+                        if (lane == 0) red[12 + wave] = m2;
+                        ev_lds_barrier();
+                        hm = fmaxf(fmaxf(red[12], red[13]), fmaxf(red[14], red[15]));
+                    }
+                    sh_lds = evh_scale_for(hm);         // this chunk's scale
 #pragma unroll
                     for (int jq = 0; jq < 8; ++jq) {
                         uint2 q0v, q1v;
@@ -4227,12 +4355,12 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
                     for (int j = 0; j < 2; ++j)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const unsigned off = base + pelem + (unsigned)((a * 2 + j) * 4 + q) * 1024u;
+                            const unsigned soff = base + (unsigned)((a * 2 + j) * 4 + q) * 1024u;      // (wave-uniform: scalar offset)
                             if (mode == 0) {
                                 const f32x4 v = {acc2[a][j][4 * q], acc2[a][j][4 * q + 1], acc2[a][j][4 * q + 2], acc2[a][j][4 * q + 3]};
-                                ev_bstore4_sc1(rPart, off, v);
+                                ev_bstore4_sc1(rPart, pelem, soff, v);
                             } else {
-                                const f32x4 v = ev_bload4_sc1(rPart, off);
+                                const f32x4 v = ev_bload4_sc1(rPart, pelem, soff);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) acc2[a][j][4 * q + e] += v[e];
                             }
@@ -4345,7 +4473,18 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
         if (lane == 0) red[wave] = mx;
         stamp(1);
         ev_lds_barrier();
-        sx = evh_scale_for(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+        float tmx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (!evh_is_finite(tmx)) {                      // (workgroup-uniform slow path, see evh_is_finite)
+            mx = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, evh_absmax4_finite(xv[r]));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            if (lane == 0) red[4 + wave] = mx;
+            ev_lds_barrier();
+            tmx = fmaxf(fmaxf(red[4], red[5]), fmaxf(red[6], red[7]));
+        }
+        sx = evh_scale_for(tmx);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             uint2 q0v, q1v;

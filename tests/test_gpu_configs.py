@@ -557,3 +557,24 @@ def test_reserved_handles_do_not_allocate_on_the_request_path(sds):
     assert 0 < m2.engine.alloc_count() <= 16 and 0 < v2.engine.alloc_count() <= 16, (m2.engine.alloc_count(), v2.engine.alloc_count())
     for o in (m, v, m2, v2):
         o.engine.close()
+
+
+
+def test_reserved_vocoder_mid_size_call_does_not_allocate(sds):
+    """the balanced builds' hand-off area (128 MiB + a synchronous memset) used to be allocated by the FIRST vocoder call
+    that picked a balanced build (a mid-size batch such as 8 x 516 frames) — on the request path, uncounted, and fatal under stream
+    capture.  It now comes with ``ev_load_vocoder`` / ``ev_reserve``: a reserved vocoder handle's first 8 x 516 call must leave
+    ``ev_alloc_count`` where it was (the 8-frame warm-up never reaches a balanced build, so it cannot hide the allocation)."""
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+
+    v = Generator(AttrDict(v1)).to(DEV)
+    v.load_state_dict(sds[1])
+    v.warmup(max_frames=516, batch=8)
+    torch.cuda.synchronize()
+    a0 = v.engine.alloc_count()
+    mel = torch.randn(8, 80, 516, generator=torch.Generator().manual_seed(3)).to(DEV) * 2 - 5
+    wav = v(mel)
+    torch.cuda.synchronize()
+    assert wav.shape == (8, 1, 516 * 256) and bool(torch.isfinite(wav).all())
+    assert v.engine.alloc_count() == a0, "the first mid-size vocoder call allocated on the request path"
+    v.engine.close()
