@@ -669,6 +669,31 @@ def main():
             cpu["parity_wav_rms"] = float((wav[:s].cpu() - ref_wav).pow(2).mean().sqrt())
             cpu["parity_wav_linf"] = float((wav[:s].cpu() - ref_wav).abs().max())
             cpu["parity_rows"] = f"rows 0..{s - 1} of the last timed step's output (batch {B})"
+        # ---- the same step with EVERY product on the exact fp32 MFMA (ev_set_arithmetic 0: v_mfma_f32_32x32x2_f32 = an fmaf chain, bit for bit),
+        # on the schedule `value` is measured on: the strict-fp32 throughput beside the headline.  The reference's
+        # arithmetic is fp32 (flow_matching.py:32-85, hifigan/models.py:181-197); the headline's products carry 22-23 significand bits.
+        fp32 = None
+        if ARITH != 0:
+            engines = [model.engine, voc.engine] + [m.engine for m in extra_models]
+            try:
+                for e in engines:
+                    e.set_arithmetic(0)
+                step(); torch.cuda.synchronize()            # warm-up: code objects of the fp32 builds
+                D.barrier()
+                tf = time.perf_counter()
+                for _ in range(3):
+                    _, wav32, mel32 = step()
+                torch.cuda.synchronize()
+                dtf = time.perf_counter() - tf
+                fp32 = {"value": round(3 * B * T * HOP / SR / dtf, 2), "unit": "audio_s/s per GPU", "ms_per_step": round(dtf / 3 * 1e3, 2), "steps": 3,
+                        "schedule": "as `value`" if pipe is not None else "serial",
+                        "mel_linf_vs_headline_arithmetic": float((mel32 - mel).abs().max()), "wav_rms_vs_headline_arithmetic": float((wav32 - wav).pow(2).mean().sqrt()),
+                        "note": "ev_set_arithmetic(0): every contraction on v_mfma_f32_32x32x2_f32 (exact fp32 multiply-add chain); same inputs, same schedule, this rank"}
+            except Exception as ex:  # noqa: BLE001 - a side record must not take the headline line down
+                log(f"[bench] fp32-MFMA step skipped: {type(ex).__name__}: {ex}")
+            finally:
+                for e in engines:
+                    e.set_arithmetic(ARITH)
         c4 = c5 = arith = None
         if world == 1 and not args.no_extras and B == 64 and T == 516:
             if pipe is not None:
@@ -702,6 +727,7 @@ def main():
             "per_gpu_audio_s_per_s": round(per_gpu, 2), "rtf": round(1.0 / per_gpu, 6), "x_realtime_per_gpu": round(per_gpu, 1),
             "serial_ms_per_step": round(serial_ms, 2), "batch_latency_ms": round(batch_latency_ms, 2), "stage_ms": stage_ms,
             "text_encoder": text_enc,
+            "value_fp32_mfma": fp32,
             "roofline": roofline, "path_roofline": path_roof, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "config4": c4, "config5": c5, "arithmetic_settings": arith,
         }

@@ -133,7 +133,14 @@ class Engine:
             raise EvLibraryError(f"ev_create failed with code {rc}")
         self.h = h
         self.spk_emb_dim = spk_emb_dim
-        self.mrf_streams_max = int(os.environ.get("EV_MRF_STREAMS_MAX", "16384"))   # the handle's default (ev_create reads the same variable)
+        env = os.environ.get("EV_MRF_STREAMS_MAX", "")   # the handle's default: ev_create reads the same variable the same way (empty = unset)
+        if env:                                          # C: `if (fp && *fp) limit = atoi(fp)` — leading integer, 0 when there is none
+            import re
+            m = re.match(r"\s*([+-]?\d+)", env)
+            self.mrf_streams_max = int(m.group(1)) if m else 0
+        else:
+            self.mrf_streams_max = 16384
+        self.pipeline_owner = None                       # {holders, saved limit} while BatchPipelines hold the vocoder's fan-out off (pipeline.py)
 
     def set_mrf_streams_max(self, max_frames: int) -> None:
         """Largest ``hifigan`` call (B*T mel frames) that runs its three ResBlock1 chains on three streams (0 = never)."""
@@ -331,7 +338,9 @@ class Engine:
         return out
 
     def set_arithmetic(self, bf16_products: int):
-        """6 (default): deep layers form each fp32 product from six exact bf16 products on the bf16 matrix pipe; 0: fp32 MFMA everywhere."""
+        """Datapath of the deep layers' products (ev_set_arithmetic).  16 (default): two block-scaled fp16 pieces per operand,
+        three fp16 products per fp32 product (22-23 significand bits, fp32 accumulation); 6: three bf16 pieces, six exact products;
+        0: every product on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 3: opt-in fast bf16 setting, NOT fp32-grade; 9: A/B."""
         self._check(self.lib.ev_set_arithmetic(self.h, int(bf16_products)), "ev_set_arithmetic")
 
     def arithmetic(self) -> int:

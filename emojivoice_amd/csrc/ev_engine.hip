@@ -568,9 +568,9 @@ constexpr int EV_CAPTURE_SLOTS = 8;       // captured ev_cfm_decode calls a hand
 constexpr int EV_SK_MAXWG = 1024;          // persistent workgroups of a balanced launch (<= 4 per CU on 256 CUs)
 constexpr int EV_SK_PART_FLOATS = 16384;   // largest partial accumulator tile handed over (64 KB: a 64 x 192 conv tile is 48 KB)
 // Hand-off area of the balanced launches: allocated once per handle (never inside a stream capture: ev_load_estimator calls this)
-int ensure_sk(ev_handle* h) {
+int ensure_sk(ev_handle* h, bool hot_path = true) {
     if (h->sk_ctrl) return 0;
-    ++h->n_allocs;             // (every loader and ev_reserve call this, so a hot call never gets here; if one ever does, ev_alloc_count shows it)
+    if (hot_path) ++h->n_allocs;   // (every loader and ev_reserve call this first, so a hot call never gets here; if one ever does, ev_alloc_count shows it)
     const size_t words = 16 + EV_SK_MAXWG;
     HIPCHK(h, hipMalloc((void**)&h->sk_ctrl, words * sizeof(unsigned)));
     HIPCHK(h, hipMemset(h->sk_ctrl, 0, words * sizeof(unsigned)));
@@ -1964,7 +1964,7 @@ int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* in
     HIPCHK(h, hipSetDevice(h->device));
     TensorMap m;
     if (build_map(h, blob, index, n, m)) return 1;
-    if (ensure_sk(h)) return 1;
+    if (ensure_sk(h, false)) return 1;
     EstimatorW& w = h->est;
     w.loaded = false;
 #define T_(k) find(h, m, k)
@@ -2112,7 +2112,7 @@ int ev_load_vocoder(ev_handle* h, const float* blob, const ev_tensor_index* inde
                 REQ(pack_conv(h, v.c2[i * 3 + j][mm], *w2, b2, 1));
             }
     }
-    REQ(ensure_sk(h));     // the balanced builds' hand-off area: a mid-size ev_hifigan call (e.g. 8 x 516 frames) takes them — never allocate on the request path
+    REQ(ensure_sk(h, false));   // the balanced builds' hand-off area: a mid-size ev_hifigan call (e.g. 8 x 516 frames) takes them — never allocate on the request path
     v.loaded = true;
     return 0;
 }
@@ -2318,7 +2318,7 @@ int ev_reserve(ev_handle* h, int B, int Tx_max, int Tp_max, int T_voc_max, void*
     HIPCHK(h, hipSetDevice(h->device));
     if (B <= 0 || Tx_max < 0 || Tp_max < 0 || T_voc_max < 0 || (Tp_max & 3)) return fail(h, "ev_reserve: bad shape B=%d Tx=%d Tp=%d (multiple of 4) T_voc=%d", B, Tx_max, Tp_max, T_voc_max);
     h->stream = (hipStream_t)stream;
-    if (ensure_sk(h)) return 1;                       // (normally there since the loaders; a handle reserved before any load gets it here)
+    if (ensure_sk(h, false)) return 1;                // (normally there since the loaders; a handle reserved before any load gets it here)
     if (Tp_max > 0 || T_voc_max > 0) {
         // the plan is monotonic in every argument except for the three-stream scratch of small vocoder calls: take the larger
         size_t need = plan_all(h, nullptr, B, Tp_max, T_voc_max, nullptr, nullptr);

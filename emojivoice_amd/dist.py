@@ -174,7 +174,9 @@ def synthesise_sharded(model, vocoder, x, x_lengths, n_timesteps, temperature=1.
     ``vocoder(MatchaTTS.synthesise(global batch)["mel"])``.  ``mel_lengths`` ride along as one extra column of the
     gathered block (exact in fp32 below 2^24 frames), so there is no second data collective.
     Failures are collective: a batch smaller than the world size raises on every rank before any collective; an out-of-range
-    token id in ONE shard raises ``IndexError`` on EVERY rank after the agreement step.
+    token id in ONE shard raises ``IndexError`` on EVERY rank after the agreement step; a failure of the decode / vocoder stage on one
+    rank (``EvLibraryError``, ``ValueError`` ...) is agreed on before the all-gather — that rank raises its exception, the others a
+    ``RuntimeError`` — so no rank is ever left waiting inside a collective.
 
     Returns ``wav`` (B, 1, 256 * y_max) for the global batch, ``mel_lengths`` (B,) int64, ``Tp``, ``y_max`` and this rank's ``mel`` shard."""
     from .text_encoder import fix_len_compatibility
@@ -190,7 +192,26 @@ def synthesise_sharded(model, vocoder, x, x_lengths, n_timesteps, temperature=1.
     Tp = fix_len_compatibility(y_max)
     if z is None:
         z = model.draw_noise(st.B, Tp)                    # ONE draw for the global batch, as the single-process run makes it
-    block, mel = shard_decode(model, vocoder, st, y_max, z, n_timesteps, temperature, denoiser=denoiser, denoiser_strength=denoiser_strength)
+    # The decode stage can fail on ONE rank only (the library refusing a shape: "exceeds the 4 GiB limit: split the batch", out of memory,
+    # a captured handle bound to another shape).  Left to propagate, that rank would raise while its peers block in the all-gather until
+    # the backend's timeout: so the failure is caught, agreed on with one more 8-byte MAX all-reduce (control plane), and raised on every
+    # rank — the failing rank re-raises its own exception, the others a RuntimeError that says which step failed elsewhere.
+    local_exc: Optional[BaseException] = None
+    block = mel = None
+    try:
+        block, mel = shard_decode(model, vocoder, st, y_max, z, n_timesteps, temperature, denoiser=denoiser, denoiser_strength=denoiser_strength)
+    except Exception as e:  # noqa: BLE001 - every failure of the stage must reach the agreement below
+        local_exc = e
+    if world > 1:
+        flag = torch.tensor([1 if local_exc is not None else 0], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else None)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        failed = bool(flag.item())
+    else:
+        failed = local_exc is not None
+    if local_exc is not None:
+        raise local_exc
+    if failed:
+        raise RuntimeError("synthesise_sharded: the decode / vocoder stage failed on another rank (its exception is raised there); no waveform was gathered")
     full = all_gather_rows(block, st.B)
     return collate_blocks(full, Tp, y_max, st.lo, st.hi, world, mel)
 

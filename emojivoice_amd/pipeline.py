@@ -30,15 +30,27 @@ class BatchPipeline:
         # The limit is the handle's: a vocoder that also serves single requests (EmojiTTS, to_waveform) gets its fan-out back
         # from close() / the context-manager exit.
         vocoder._sync_engine()
-        self._mrf_restore = vocoder.engine.mrf_streams_max
-        vocoder.engine.set_mrf_streams_max(0)
+        # The limit is saved ONCE per engine, by the first pipeline that takes it away, and given back when the last one closes: a second
+        # pipeline built on the same vocoder before the first was closed used to save the 0 the first one had set and "restore" that — the
+        # fan-out was lost for good.
+        eng = vocoder.engine
+        if eng.pipeline_owner is None:
+            eng.pipeline_owner = {"holders": 0, "saved": eng.mrf_streams_max}
+            eng.set_mrf_streams_max(0)
+        eng.pipeline_owner["holders"] += 1
+        self._holding = True
 
     def close(self) -> None:
         """Drain both streams and give the vocoder engine its small-call three-stream fan-out limit back."""
         self.synchronize()
-        if self._mrf_restore is not None and self.vocoder.engine is not None:
-            self.vocoder.engine.set_mrf_streams_max(self._mrf_restore)
-            self._mrf_restore = None
+        eng = self.vocoder.engine
+        if self._holding and eng is not None and eng.pipeline_owner is not None:
+            self._holding = False
+            eng.pipeline_owner["holders"] -= 1
+            if eng.pipeline_owner["holders"] <= 0:
+                if eng.h:
+                    eng.set_mrf_streams_max(eng.pipeline_owner["saved"])
+                eng.pipeline_owner = None
 
     def __enter__(self):
         return self

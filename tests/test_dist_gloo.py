@@ -177,16 +177,36 @@ def _synth_body(rank, world, port, q):
         small = "no error"
     except ValueError:
         small = "ValueError"
-    q.put((rank, out["Tp"], Tp, tuple(out["wav"].shape), int(ref["mel_lengths"].max()), e_mel, e_wav, same_len, out["ranks"], collective_error, small))
+    # a failure of the decode / vocoder stage on ONE rank (here: rank 1's vocoder raises, as the library does for an over-size tensor):
+    # rank 1 raises its own exception, rank 0 a RuntimeError — neither is left inside the all-gather
+    def flaky_vocoder(mel):
+        if rank == 1:
+            raise ValueError("tensor exceeds the 4 GiB buffer-addressing limit: split the batch")
+        return vocoder(mel)
+    try:
+        torch.manual_seed(4242)
+        D.synthesise_sharded(model, flaky_vocoder, ids, xl, 2, 0.667, spks, 1.0)
+        stage_error = "no error"
+    except ValueError as e:
+        stage_error = "ValueError" if "4 GiB" in str(e) else "other ValueError"
+    except RuntimeError as e:
+        stage_error = "RuntimeError" if "another rank" in str(e) else "other RuntimeError"
+    # ... and the group is still usable afterwards
+    torch.manual_seed(4242)
+    again = D.synthesise_sharded(model, vocoder, ids, xl, 2, 0.667, spks, 1.0)
+    usable = bool(torch.equal(again["wav"], out["wav"]))
+    q.put((rank, out["Tp"], Tp, tuple(out["wav"].shape), int(ref["mel_lengths"].max()), e_mel, e_wav, same_len, out["ranks"], collective_error, small, stage_error, usable))
     D.barrier()
     dist.destroy_process_group()
 
 
 def test_synthesise_sharded_equals_single_process():
-    for rank, tp, want_tp, shape, y_max, e_mel, e_wav, same_len, ranks, collective_error, small in _spawn(_worker_synth, timeout=600):
+    for rank, tp, want_tp, shape, y_max, e_mel, e_wav, same_len, ranks, collective_error, small, stage_error, usable in _spawn(_worker_synth, timeout=600):
         assert ranks == 2 and tp == want_tp
         assert shape == (5, 1, 256 * y_max)                    # the vocoder saw the mel trimmed to max(y_lengths), as synthesise returns it
         assert same_len                                        # mel_lengths ride along in the one gather, exact
         assert e_mel <= 1e-5 and e_wav <= 1e-5, (rank, e_mel, e_wav)
         assert collective_error == "IndexError", (rank, collective_error)   # raised on BOTH ranks (the bad id sits in rank 1's shard)
         assert small == "ValueError"
+        assert stage_error == ("ValueError" if rank == 1 else "RuntimeError"), (rank, stage_error)   # the failing rank: its own exception; the other: told so
+        assert usable
