@@ -36,6 +36,7 @@ struct ConvLayer {
     unsigned short* Wh = nullptr; float wh_scale = 1.f;   // the weights times wh_scale (a power of two: the largest lands in [8192, 16384)) as two fp16
                                     // pieces in conv_h16_kernel's fragment order (Kpad % 16 == 0)
     unsigned short* Wx = nullptr;   // the same weights as three bf16 pieces in conv_split_kernel's fragment order (Kpad % 64 == 0 only)
+    unsigned short* Wq = nullptr;   // the two fp16 pieces of Wh in v_mfma_f32_16x16x32_f16 fragment order (conv_h16_kernel<..., Q = 1>; Kpad % 64 == 0 only)
     float* bias = nullptr;    // [Cout] (stacked / phase-replicated as needed) or null
     int2* taplist[3] = {nullptr, nullptr, nullptr};   // for BM = 128, 64, 32: [mtiles][EV_MAX_TAPS] {tap, row offset} (one shared row when dense)
     int* nact[3] = {nullptr, nullptr, nullptr};       // per-tile active tap count (null when dense)
@@ -246,6 +247,22 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                             Whp[base] = hbits(h0); Whp[base + 512] = hbits(h1);
                         }
         if (dev_upload(h, Whp, &L.Wh)) return 1;
+        if (L.Kpad % 32 == 0) {   // ... and in the 16 x 16 x 32 fragment order [tap][Mpad/16][Kpad/32][piece][lane][8]: lane = (row & 15) + 16 kgroup, k = 32 kg32 + 8 kgroup + e
+            const int MT16 = L.Mpad / 16, KG32 = L.Kpad / 32;
+            std::vector<unsigned short> Wqp(Wh.size() * 2);
+            for (int tap = 0; tap < L.ntaps; ++tap)
+                for (int mt = 0; mt < MT16; ++mt)
+                    for (int kg = 0; kg < KG32; ++kg)
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int e = 0; e < 8; ++e) {
+                                const int row = mt * 16 + (lane & 15), kk = kg * 32 + 8 * (lane >> 4) + e;
+                                const float w = Wh[((size_t)tap * L.Mpad + row) * L.Kpad + kk] * L.wh_scale;
+                                const _Float16 h0 = (_Float16)w, h1 = (_Float16)(w - (float)h0);
+                                const size_t base = ((((size_t)tap * MT16 + mt) * KG32 + kg) * 2) * 512 + (size_t)lane * 8 + e;
+                                Wqp[base] = hbits(h0); Wqp[base + 512] = hbits(h1);
+                            }
+            if (dev_upload(h, Wqp, &L.Wq)) return 1;
+        }
     }
     if (L.Kpad % 16 == 0) {   // conv_split_kernel / resblock_pair_split_kernel: w = w0 + w1 + w2 exactly, each piece the upper half of an fp32 word (bf16);
         // order [tap][Mpad/32][Kpad/16][piece][lane][8], lane = (row & 31) + 32 * half, element e <-> k = 16 kg + 8 half + e
@@ -525,6 +542,13 @@ void launch_h16(const ConvParams& p, hipStream_t st, const LaunchOpts& lo) {
     constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4) * sizeof(float);
     const size_t smem = xs > es ? xs : es;
     const dim3 grid(p.mtiles * p.ntiles);
+    // the 16 x 16 x 32 K loop (conv_h16_kernel<..., Q = 1>) wherever the layer carries that fragment order; EV_H16Q=0: the 32 x 32 x 16 form (A/B)
+    static const bool use_q = !(getenv("EV_H16Q") && atoi(getenv("EV_H16Q")) == 0);
+    if (use_q && p.Wq && p.act != ACT_SNAKE) {
+        if (lean_acc(p)) { ensure_dyn_smem<conv_h16_kernel<BM, BN, WM, WN, 3, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_kernel<BM, BN, WM, WN, 3, 1>), grid, dim3(256), smem, st, p); }
+        else { ensure_dyn_smem<conv_h16_kernel<BM, BN, WM, WN, 1, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_kernel<BM, BN, WM, WN, 1, 1>), grid, dim3(256), smem, st, p); }
+        return;
+    }
     if (p.act == ACT_SNAKE) { ensure_dyn_smem<conv_h16_kernel<BM, BN, WM, WN, 2>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_kernel<BM, BN, WM, WN, 2>), grid, dim3(256), smem, st, p); }
     else if (lean_acc(p)) { ensure_dyn_smem<conv_h16_kernel<BM, BN, WM, WN, 3>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_kernel<BM, BN, WM, WN, 3>), grid, dim3(256), smem, st, p); }
     else { ensure_dyn_smem<conv_h16_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_kernel<BM, BN, WM, WN, 1>), grid, dim3(256), smem, st, p); }
@@ -705,7 +729,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     memset(&p, 0, sizeof p);
     h->gn_stats_tiles = 0;
     p.X = X; p.ldx = ldx; p.Cin = L.Cin; p.isplit_log2 = e.isplit_log2; p.isstride = e.isstride;
-    p.W = L.W; p.Wx = L.Wx; p.Wh = L.Wh; p.wh_scale = L.wh_scale; p.Mpad = L.Mpad; p.Kpad = L.Kpad; p.bias = L.bias;
+    p.W = L.W; p.Wx = L.Wx; p.Wh = L.Wh; p.Wq = L.Wq; p.wh_scale = L.wh_scale; p.Mpad = L.Mpad; p.Kpad = L.Kpad; p.bias = L.bias;
     p.Y = Y; p.ldy = ldy; p.Cout = L.Cout; p.osplit_log2 = e.osplit_log2; p.osstride = e.osstride; p.mmul = e.mmul;
     p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T;
     p.ntaps = L.ntaps; for (int i = 0; i < L.ntaps; ++i) p.off[i] = L.off[i];
@@ -953,7 +977,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     p.ntaps = L2.ntaps; p.taplist = L2.taplist[0]; p.tl_stride = 0; p.nact_tab = nullptr;
     p.pro_lrelu = 1; p.pro_slope = 0.1f;
     p.scale = 1.f; p.R = X; p.ldr = C; p.accum = e.accum; p.div3 = e.div3; p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope;
-    pp.W1 = L1.W; pp.W1x = L1.Wx; p.Wx = L2.Wx; pp.W1h = L1.Wh; pp.w1h_scale = L1.wh_scale; p.Wh = L2.Wh; p.wh_scale = L2.wh_scale; pp.b1 = L1.bias; pp.taplist1 = L1.taplist[0]; pp.ntaps1 = L1.ntaps;
+    pp.W1 = L1.W; pp.W1x = L1.Wx; p.Wx = L2.Wx; pp.W1h = L1.Wh; pp.w1h_scale = L1.wh_scale; p.Wh = L2.Wh; p.wh_scale = L2.wh_scale; pp.W1q = L1.Wq; p.Wq = L2.Wq; pp.b1 = L1.bias; pp.taplist1 = L1.taplist[0]; pp.ntaps1 = L1.ntaps;
     pp.h1 = L1.halo_lo; pp.h2 = L2.halo_lo; pp.mid_slope = 0.1f;
     if ((double)g.nrows * C * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
     if (L1.sparse_taps || L2.sparse_taps || L1.Kpad != C || L2.Kpad != C || L1.Kpad != L2.Kpad || L1.Mpad != L2.Mpad || L1.halo_lo != L1.halo_hi ||
@@ -978,8 +1002,13 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
         pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
         const size_t smem = std::max((size_t)(NT + EV_HALO) * RSB + 64, (size_t)4 * 32 * 36 * sizeof(float));   // (+ 16 floats: the waves' maxima)
         const dim3 grid(p.ntiles);
+        // both K loops on v_mfma_f32_16x16x32_f16 (resblock_pair_h16q_kernel) wherever the layers carry that fragment order; EV_H16Q=0: the 32 x 32 x 16 form (A/B)
+        static const bool use_q = !(getenv("EV_H16Q") && atoi(getenv("EV_H16Q")) == 0);
+        const bool q = use_q && L1.Wq && L2.Wq;
 #define EV_PAIR_H16(WM, WN) do { \
-            if (lean == 1) { ensure_dyn_smem<resblock_pair_h16_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_h16_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, pp); } \
+            if (q && lean == 1) { ensure_dyn_smem<resblock_pair_h16q_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_h16q_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, pp); } \
+            else if (q) { ensure_dyn_smem<resblock_pair_h16q_kernel<WM, WN, 3>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_h16q_kernel<WM, WN, 3>), grid, dim3(256), smem, h->stream, pp); } \
+            else if (lean == 1) { ensure_dyn_smem<resblock_pair_h16_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_h16_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, pp); } \
             else { ensure_dyn_smem<resblock_pair_h16_kernel<WM, WN, 3>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_h16_kernel<WM, WN, 3>), grid, dim3(256), smem, h->stream, pp); } } while (0)
         if (C == 32) EV_PAIR_H16(1, 4); else if (C == 64) EV_PAIR_H16(2, 2); else EV_PAIR_H16(4, 1);
 #undef EV_PAIR_H16

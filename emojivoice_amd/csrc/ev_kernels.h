@@ -53,6 +53,7 @@ struct ConvParams {
     int isplit_log2, isstride;              // input column ci lives at (ci >> isplit_log2)*isstride + (ci & (2^isplit_log2 - 1))
     const float* W; int Mpad; int Kpad;     // fragment order [ntaps][Mpad/32][Kpad/8][64 lanes][4]
     const void* Wh; float wh_scale;         // conv_h16_kernel: the weights times wh_scale (a power of two) as two fp16 pieces, [ntaps][Mpad/32][Kpad/16][2][64 lanes][8]
+    const void* Wq;                         // conv_h16_kernel<..., Q = 1>: the same pieces in v_mfma_f32_16x16x32_f16 fragment order, [ntaps][Mpad/16][Kpad/32][2][64 lanes][8] (null: not packed)
     const void* Wx;                         // conv_split_kernel: the same weights as three bf16 pieces, [ntaps][Mpad/32][Kpad/16][3][64 lanes][8] (null: not packed)
     const float* bias;                      // [Cout] or null
     float* Y; int ldy; int Cout;
@@ -143,6 +144,15 @@ __device__ __forceinline__ float ev_silu(float x) { return x / (1.f + expf(-x));
 // pi/2 with three fma steps, the cephes single-precision sine polynomial on |r| <= pi/4, and sin^2 = 1 - sin^2 on odd
 // quadrants.  Absolute error <= 2e-7 for |u| <= 1e4 (hidden activations are O(10)); degrades gracefully beyond that.
 __device__ __forceinline__ float ev_sin2(float u) {
+#ifdef EV_SIN2_HW
+    // A/B build (-DEV_SIN2_HW): the hardware cosine.  sin^2 has period pi: Cody-Waite reduction by pi in two fma steps (r in [-pi/2, pi/2]), then
+    // sin^2 r = (1 - cos 2r) / 2 with v_cos_f32, whose argument is in revolutions (2r / 2pi = r / pi).  ~8 issue slots instead of ~15; absolute
+    // error against fp64 2.0e-7 max / 4.2e-8 rms over |u| <= 1000, against 1.1e-7 / 2.1e-8 for the polynomial (tools/sin2_probe.hip).
+    const float kk = rintf(u * 0.318309886183790672f);
+    float rr = fmaf(kk, -3.1415927410125732421875f, u);
+    rr = fmaf(kk, 8.742277657347586e-8f, rr);
+    return fmaf(__builtin_amdgcn_cosf(rr * 0.318309886183790672f), -0.5f, 0.5f);
+#endif
     const float k = rintf(u * 0.63661977236758134f);
     float r = fmaf(k, -1.57079637050628662109375f, u);
     r = fmaf(k, 4.371138828673793e-8f, r);
@@ -314,15 +324,16 @@ __device__ __forceinline__ float ev_div3(float x) {   // correctly rounded x / 3
 struct EvNoHook { __device__ __forceinline__ void operator()() const {} };
 // `after_issue` runs between the request of the first slab's residual / mask rows and the barrier in front of the transposition
 // (conv_gemm_sk_kernel sums its partial tiles there, in the shadow of those loads; it may still modify acc).
-template <int TM, int TN, int MODE = 1, class Hook = EvNoHook>
-__device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane,
-                                                   int win_lo = -0x7fffffff, int win_hi = 0x7fffffff, Hook after_issue = Hook()) {
+// `put_slab(j)` writes the wave's accumulators of the 32-frame slab j to Es as [frame][channel] (row stride TM * 32 + 4): the two accumulator
+// layouts (32 x 32 tiles of v_mfma_f32_32x32x*, 16 x 16 tiles of v_mfma_f32_16x16x32_f16) differ only there.
+template <int TM, int TN, int MODE, class Hook, class PutSlab>
+__device__ __forceinline__ void conv_epilogue_lean_impl(const ConvParams& p, PutSlab put_slab, float* Es, int mw0, int nw0, int lane,
+                                                        int win_lo, int win_hi, Hook after_issue) {
     constexpr int EC = TM * 32, ELD = EC + 4, C4 = EC / 4, RPP = 64 / C4, NP = 32 / RPP;
     // Everything per-lane below derives from `lane`.  Left visible, hipcc computes these offsets — loop invariants of the callers' tile /
     // chunk loops — at the top of the kernel and keeps them in registers through the K loop; in the persistent builds that cost 30-60
     // registers and put conv_h16_bal_kernel / ln_mlp_h16_kernel into scratch (round 3).  The empty asm makes them start HERE.
     asm volatile("" : "+v"(lane));
-    const int li = lane & 31, lh = lane >> 5;
     const int er = lane / C4, ec = (lane % C4) * 4;
     const int co = mw0 + ec;
     const bool co_ok = co < p.Cout;
@@ -381,13 +392,7 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         // per-wave transposition through this wave's private LDS slab (ordered by the wave's own program order)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 q4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                *(f32x4*)(Es + li * ELD + i * 32 + 8 * g + 4 * lh) = q4;
-            }
+        put_slab(j);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -420,6 +425,38 @@ __device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next slab overwrites Es
     }
+}
+template <int TM, int TN, int MODE = 1, class Hook = EvNoHook>
+__device__ __forceinline__ void conv_epilogue_lean(const ConvParams& p, f32x16 (&acc)[TM][TN], float* Es, int mw0, int nw0, int lane,
+                                                   int win_lo = -0x7fffffff, int win_hi = 0x7fffffff, Hook after_issue = Hook()) {
+    // C/D layout of a 32x32 tile: col = lane & 31 (frame), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (channel)
+    auto put = [&](int j) {
+        constexpr int ELD = TM * 32 + 4;
+        const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 q4 = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *(f32x4*)(Es + li * ELD + i * 32 + 8 * g + 4 * lh) = q4;
+            }
+    };
+    conv_epilogue_lean_impl<TM, TN, MODE>(p, put, Es, mw0, nw0, lane, win_lo, win_hi, after_issue);
+}
+// ... for accumulators in 16 x 16 tiles (v_mfma_f32_16x16x32_f16): acc[a][b] = channels 16 a + 4 (lane >> 4) + 0..3 of frame 16 b + (lane & 15);
+// TM / TN count 32-wide units as above (the wave tile is 2 TM x 2 TN tiles of 16 x 16)
+template <int TM, int TN, int MODE = 1>
+__device__ __forceinline__ void conv_epilogue_lean_q(const ConvParams& p, f32x4 (&acc)[2 * TM][2 * TN], float* Es, int mw0, int nw0, int lane,
+                                                     int win_lo = -0x7fffffff, int win_hi = 0x7fffffff) {
+    auto put = [&](int j) {
+        constexpr int ELD = TM * 32 + 4;
+        const int f = lane & 15, kg = lane >> 4;
+#pragma unroll
+        for (int b2 = 0; b2 < 2; ++b2)
+#pragma unroll
+            for (int a = 0; a < 2 * TM; ++a) *(f32x4*)(Es + (b2 * 16 + f) * ELD + a * 16 + 4 * kg) = acc[a][2 * j + b2];
+    };
+    conv_epilogue_lean_impl<TM, TN, MODE>(p, put, Es, mw0, nw0, lane, win_lo, win_hi, EvNoHook());
 }
 
 // ---------------------------------------------------------------------------
@@ -1323,7 +1360,12 @@ __device__ __forceinline__ void evh_mma(f32x16 (&acc)[TM][TN], const f32x4 (&a)[
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[PA[t]][i]), __builtin_bit_cast(f16x8, b[PB[t]][j]), acc[i][j], 0, 0, 0);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN>
+// Q = 1: the K loop on v_mfma_f32_16x16x32_f16 (16 x 16 output tiles, 32-deep steps) instead of v_mfma_f32_32x32x16_f16.  Same FLOP per
+// cycle, same operand bytes per FLOP at the same 64 x 64 wave tile — but under this chip's power limit the 16 x 16 shape holds a higher clock:
+// tools/mfma_shape_probe.hip (LDS + L2 fed loop of this kernel's shape, random data, two waves per SIMD): 1254 vs 1444 TFLOP/s executed,
+// 1.52 vs 1.72 GHz (profiles/r04_mfma_shape_probe.txt; MI355X_MICROARCH.md, DVFS give-back item 7).  Weights: p.Wq, the same two fp16 pieces in
+// the 16 x 16 x 32 fragment order [tap][Mpad/16][Kpad/32][piece][64 lanes][8]: lane = (row & 15) + 16 kgroup, element e = k 32 kg32 + 8 kgroup + e.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN, int Q = 0>
 __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
@@ -1386,9 +1428,29 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
     const char* bbase = Xb + (wn * (TN * 32) + li + p.halo_lo) * EVH_RSB + 16 * lh;
     const int2 tlv = (lane < nact) ? tl[lane] : make_int2(0, 0);
     const int2 tv_first = ev_tap_at(tlv, 0);
-    if (nact > 0) {
-        const unsigned a0 = a_off(tv_first.x, 0);
-        ldAp(A0, a0); ldAp(A1, a0 + 2048u); ldAp(A2, a0 + 4096u); ldAp(A3, a0 + 6144u);
+    // the 16 x 16 x 32 form's fragments (Q = 1; unused and eliminated otherwise)
+    constexpr int QM = 2 * TM, QN = 2 * TN;            // 16 x 16 tiles of the wave tile
+    const int f16i = lane & 15, kg = lane >> 4;        // frame (column) inside a tile / 8-deep k group of the 32-deep step
+    const __amdgpu_buffer_rsrc_t rQ = ev_rsrc(p.Wq);
+    const int KG32 = p.Kpad >> 5;
+    const unsigned qbase = (unsigned)(((m0 + wm * (TM * 32)) >> 4) * KG32) * 2048u;
+    // fragment (tile a, piece pc) of the 32-deep step kg32 of a tap: tap bytes + ((m16 KG32 + kg32) 2 + pc) KiB
+    auto q_off = [&](int tap_bytes, int kg32) -> unsigned { return (unsigned)tap_bytes + qbase + (unsigned)kg32 * 2048u; };
+    f32x4 QA0[2][QM], QA1[2][QM], QB0[2][QN], QB1[2][QN];
+    auto ldQA = [&](f32x4 (&dst)[2][QM], unsigned aoff) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int a = 0; a < QM; ++a) dst[pc][a] = ev_bload4(rQ, wlane, aoff + (unsigned)(a * KG32 * 2048 + pc * 1024));
+    };
+    if (nact > 0) {                                     // the first tap's fragments fly under the pre-scan
+        if constexpr (Q == 0) {
+            const unsigned a0 = a_off(tv_first.x, 0);
+            ldAp(A0, a0); ldAp(A1, a0 + 2048u); ldAp(A2, a0 + 4096u); ldAp(A3, a0 + 6144u);
+        } else {
+            const unsigned a0 = q_off(tv_first.x, 0);
+            ldQA(QA0, a0); ldQA(QA1, a0 + 2048u);
+        }
     }
     unsigned xoff[XPASS];
 #pragma unroll
@@ -1431,26 +1493,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
     const float acc_in = p.wh_scale * xs;              // bias in accumulator units
     const float acc_out = 1.0f / acc_in;               // (both powers of two: exact)
 
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        f32x4 bq[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            bq[g] = z;
-            const int c0 = m0 + wm * (TM * 32) + a * 32 + 8 * g + 4 * lh;
-            if (p.bias && c0 < p.Cout) bq[g] = *(const f32x4*)(p.bias + c0) * acc_in;
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = bq[r >> 2][r & 3];
-    }
-
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __builtin_amdgcn_s_setprio(3);
-        ev_lds_barrier();                               // the previous chunk's MFMAs are done with the tile
+    auto stage = [&](int ch) {                          // chunk ch of the X tile: prologue, scale, split, LDS
         {
             const unsigned soff = evx_chunk_off(p, ch);
 #pragma unroll
@@ -1476,6 +1519,29 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
                 }
             }
         }
+    };
+    if constexpr (Q == 0) {
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        f32x4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            bq[g] = z;
+            const int c0 = m0 + wm * (TM * 32) + a * 32 + 8 * g + 4 * lh;
+            if (p.bias && c0 < p.Cout) bq[g] = *(const f32x4*)(p.bias + c0) * acc_in;
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = bq[r >> 2][r & 3];
+    }
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __builtin_amdgcn_s_setprio(3);
+        ev_lds_barrier();                               // the previous chunk's MFMAs are done with the tile
+        stage(ch);
         ev_lds_barrier();
         __builtin_amdgcn_s_setprio(0);
         const char* brow = bbase + tv_first.y * EVH_RSB;
@@ -1517,6 +1583,69 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] *= acc_out;
     __builtin_amdgcn_s_setprio(3);
     conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    } else {
+        // ---------------- the 16 x 16 x 32 form ----------------
+        f32x4 acc[QM][QN];
+#pragma unroll
+        for (int a = 0; a < QM; ++a) {
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            const int c0 = m0 + wm * (TM * 32) + a * 16 + 4 * kg;   // C/D layout: rows 4 (lane >> 4) + 0..3 of tile a
+            if (p.bias && c0 < p.Cout) bq = *(const f32x4*)(p.bias + c0) * acc_in;
+#pragma unroll
+            for (int b = 0; b < QN; ++b) acc[a][b] = bq;
+        }
+        // B fragment of step ks (32 channels of the 64-channel chunk): lane = frame (lane & 15) of tile b, 8 channels 8 (lane >> 4) ..
+        auto ldQB = [&](f32x4 (&dst)[2][QN], const char* brow, int ks) {
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+                for (int b = 0; b < QN; ++b) dst[pc][b] = *(const f32x4*)(brow + b * 16 * EVH_RSB + pc * (EVX_KC * 2) + ks * 64);
+        };
+        auto mmaQ = [&](const f32x4 (&a)[2][QM], const f32x4 (&b)[2][QN]) {
+            constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < QM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < QN; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[PA[t]][i]), __builtin_bit_cast(f16x8, b[PB[t]][jj]), acc[i][jj], 0, 0, 0);
+        };
+        const char* qbb = Xb + (wn * (TN * 32) + f16i + p.halo_lo) * EVH_RSB + 16 * kg;
+        for (int ch = 0; ch < nchunks; ++ch) {
+            __builtin_amdgcn_s_setprio(3);
+            ev_lds_barrier();                           // the previous chunk's MFMAs are done with the tile
+            stage(ch);
+            ev_lds_barrier();
+            __builtin_amdgcn_s_setprio(0);
+            const char* brow = qbb + tv_first.y * EVH_RSB;
+            ldQB(QB0, brow, 0);
+            for (int ti = 0; ti < nact; ++ti) {
+                const bool last_tap = (ti + 1 == nact);
+                const int2 ntv = last_tap ? tv_first : ev_tap_at(tlv, ti + 1);
+                const char* nbrow = qbb + ntv.y * EVH_RSB;
+                const bool have_next = !(last_tap && ch + 1 == nchunks);
+                const unsigned nap = have_next ? q_off(ntv.x, last_tap ? ch * 2 + 2 : ch * 2) : q_off(tv_first.x, 0);   // unconditional loads
+                ldQB(QB1, brow, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                mmaQ(QA0, QB0);
+                __builtin_amdgcn_sched_barrier(0);
+                ldQA(QA0, nap);
+                ldQB(QB0, nbrow, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mmaQ(QA1, QB1);
+                __builtin_amdgcn_sched_barrier(0);
+                ldQA(QA1, nap + 2048u);
+                brow = nbrow;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < QM; ++a)
+#pragma unroll
+            for (int b = 0; b < QN; ++b) acc[a][b] *= acc_out;
+        __builtin_amdgcn_s_setprio(3);
+        conv_epilogue_lean_q<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -2485,6 +2614,7 @@ struct PairParams {
     ConvParams c2;                 // c2 + epilogue view: X = x (input), W/bias/taplist = c2's, R = x, Y = output, flags
     const float* W1; const float* b1; const int2* taplist1; int ntaps1;
     const void* W1h; float w1h_scale;   // resblock_pair_h16_kernel: c1's weights times w1h_scale as two fp16 pieces (c2's: c2.Wh, c2.wh_scale)
+    const void* W1q;               // resblock_pair_h16q_kernel: the same pieces in the 16 x 16 x 32 fragment order (c2's: c2.Wq)
     const void* W1x;               // resblock_pair_split_kernel: c1's weights as three bf16 pieces (c2's: c2.Wx)
     int h1, h2;                    // halos of c1 (dilated) and c2
     float mid_slope;               // leaky-relu slope between the convs
@@ -3061,6 +3191,225 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16_kernel(const PairPar
             for (int r16 = 0; r16 < 16; ++r16) acc[0][j][r16] *= inv2;
     }
     conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
+}
+
+// ---------------------------------------------------------------------------
+// resblock_pair_h16q_kernel: resblock_pair_h16_kernel with both K loops on v_mfma_f32_16x16x32_f16 (see conv_h16_kernel<..., Q = 1>: the 16 x 16
+// shape holds a higher clock under the chip's power limit).  A "group" of the K loops — two 16-deep slabs of one tap — is exactly one 32-deep
+// step here; a wave's 32 channels x 64 frames are 2 x 4 tiles of 16 x 16.  Weights: W1q / c2.Wq (16 x 16 x 32 fragment order), same pieces,
+// same scales, same accumulation order over (tap, k) as the 32 x 32 form; LDS layout, staging, scale search and epilogue are unchanged.
+// ---------------------------------------------------------------------------
+template <int WAVES_M, int WAVES_N, int LEAN>
+__global__ __launch_bounds__(256, 2) void resblock_pair_h16q_kernel(const PairParams pp) {
+    constexpr int TM = 1, TN = 2, QM = 2, QN = 4;
+    constexpr int C = 32 * WAVES_M;
+    constexpr int NT = WAVES_N * TN * 32;
+    constexpr int RSB = 4 * C + 16;                     // LDS row stride in bytes
+    constexpr int H = C / 32;                           // 32-deep steps per tap
+    constexpr int TPR = C / 4, RPS = 256 / TPR;         // staging: threads per row, rows per pass
+    constexpr int XPASS = (NT + EV_HALO) / RPS;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+    const ConvParams& p = pp.c2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;                             // phase 1: [NT + 2 h1][RSB];  phase 2 (aliased): y1 [NT + 2 h2][RSB]
+    float* red = smem + ((NT + EV_HALO) * RSB) / 4;     // 16 floats behind the tiles: the waves' maxima (x: 0..3, y1: 4..7; their finite-only repeats: 8..11, 12..15)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int f16i = lane & 15, kg = lane >> 4;         // frame inside a 16-wide tile / 8-deep k group (= channel group 4 kg .. of a C/D tile)
+    const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
+
+    const int nt = ev_xcd_remap(blockIdx.x, p.ntiles);
+    const int n0 = nt * pp.out_rows;
+    const int g0 = n0 - pp.h2;
+    {   // tiles whose output window holds no storable row do nothing
+        const int s0 = n0 % p.S, t_first = s0 - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - s0 + p.P;
+        if (dist >= pp.out_rows || n0 + dist >= p.nrows) return;
+    }
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned wbase = (unsigned)(wm * 2 * H) * 2048u;   // this wave's two 16-channel row tiles: m16 = 2 wm + a, H steps of 2 KiB each
+    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(p.X);
+    f32x4 acc[QM][QN];
+    f32x4 A0[2][QM], A1[2][QM], B0[2][QN], B1[2][QN];
+
+    auto ldA = [&](const __amdgpu_buffer_rsrc_t& rW, f32x4 (&dst)[2][QM], unsigned aoff) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int a = 0; a < QM; ++a) dst[pc][a] = ev_bload4(rW, wlane, aoff + (unsigned)(a * H * 2048 + pc * 1024));
+    };
+    auto ldB = [&](f32x4 (&dst)[2][QN], const char* brow, int ks) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int b = 0; b < QN; ++b) dst[pc][b] = *(const f32x4*)(brow + b * 16 * RSB + pc * (2 * C) + ks * 64);
+    };
+    // step g of a phase = the 32-deep step g % H of tap g / H (a tap's plane is as large as its fp32 plane: the tap list's byte offsets apply)
+    auto g_off = [&](int2 tlv, int g, int nsteps) -> unsigned {
+        const int gg = g < nsteps ? g : 0;              // (beyond the phase: a harmless re-read)
+        return (unsigned)__builtin_amdgcn_readlane(tlv.x, gg / H) + wbase + (unsigned)(gg % H) * 2048u;
+    };
+    auto g_row = [&](int2 tlv, int g, int nsteps) -> int {
+        const int gg = g < nsteps ? g : 0;
+        return __builtin_amdgcn_readlane(tlv.y, gg / H);
+    };
+    auto acc_init = [&](const float* binit, float unit) {   // bias in accumulator units; C/D rows 4 kg + 0..3 of tile a
+#pragma unroll
+        for (int a = 0; a < QM; ++a) {
+            const f32x4 bq = *(const f32x4*)(binit + wm * 32 + a * 16 + 4 * kg) * unit;
+#pragma unroll
+            for (int b = 0; b < QN; ++b) acc[a][b] = bq;
+        }
+    };
+    auto mma = [&](const f32x4 (&a)[2][QM], const f32x4 (&b)[2][QN]) {
+        constexpr int PA[3] = {0, 1, 0}, PB[3] = {1, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int i = 0; i < QM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < QN; ++jj)
+                    acc[i][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a[PA[t]][i]), __builtin_bit_cast(f16x8, b[PB[t]][jj]), acc[i][jj], 0, 0, 0);
+    };
+    auto ring_fill = [&](const __amdgpu_buffer_rsrc_t& rW, int2 tlv, int nsteps) {
+        ldA(rW, A0, g_off(tlv, 0, nsteps)); ldA(rW, A1, g_off(tlv, 1, nsteps));
+    };
+    auto kloop = [&](const __amdgpu_buffer_rsrc_t& rW, int2 tlv, int nsteps, const char* bbase) {
+        auto step = [&](f32x4 (&Aa)[2][QM], f32x4 (&Bc)[2][QN], f32x4 (&Bn)[2][QN], int g) {
+            const char* nbrow = bbase + g_row(tlv, g + 1, nsteps) * RSB;
+            ldB(Bn, nbrow, (g + 1) % H);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(Aa, Bc);
+            __builtin_amdgcn_sched_barrier(0);
+            ldA(rW, Aa, g_off(tlv, g + 2, nsteps));
+        };
+        ldB(B0, bbase + g_row(tlv, 0, nsteps) * RSB, 0);
+        int g = 0;
+        for (; g + 1 < nsteps; g += 2) { step(A0, B0, B1, g); step(A1, B1, B0, g + 1); }
+        if (g < nsteps) step(A0, B0, B1, g);
+    };
+    auto wg_max = [&](float mx, int slot) -> float {        // workgroup maximum through LDS (one barrier)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) red[slot + wave] = mx;
+        ev_lds_barrier();
+        return fmaxf(fmaxf(red[slot], red[slot + 1]), fmaxf(red[slot + 2], red[slot + 3]));
+    };
+
+    // ---------------- phase 1: c1 over lrelu(x); X tile rows [g0 - h1, g0 + NT + h1), all channels, loaded once
+    const __amdgpu_buffer_rsrc_t rW1 = ev_rsrc(pp.W1q), rW2 = ev_rsrc(p.Wq);
+    const int ng1 = pp.ntaps1 * H, ng2 = p.ntaps * H;
+    const int2 tlv1 = (lane < pp.ntaps1) ? pp.taplist1[lane] : make_int2(0, 0);
+    const int2 tlv2 = (lane < p.ntaps) ? p.taplist[lane] : make_int2(0, 0);
+    ring_fill(rW1, tlv1, ng1);
+    float sx;
+    {
+        const int xrows = NT + 2 * pp.h1;
+        f32x4 xg[XPASS];
+        float mx = 0.f;
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) {
+            const int r = q * RPS + srow;
+            const int gr = g0 - pp.h1 + r;
+            xg[q] = ev_bload4(rX, ((r < xrows && gr >= 0 && gr < p.nrows) ? (unsigned)gr * (unsigned)p.ldx : 0u) * 4u + (unsigned)sc4 * 4u, 0);   // (row 0 is a zero pad row)
+        }
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) mx = fmaxf(mx, evh_absmax4(xg[q]));
+        float tmx = wg_max(mx, 0);                      // (|lrelu(x)| <= |x|)
+        if (!evh_is_finite(tmx)) {                      // an Inf in the tile (workgroup-uniform): the finite maximum sets the scale
+            mx = 0.f;
+#pragma unroll
+            for (int q = 0; q < XPASS; ++q) mx = fmaxf(mx, evh_absmax4_finite(xg[q]));
+            tmx = wg_max(mx, 8);
+        }
+        sx = evh_scale_for(tmx);
+#pragma unroll
+        for (int q = 0; q < XPASS; ++q) {
+            const int r = q * RPS + srow;
+            f32x4 v = xg[q];
+            v[0] = ev_lrelu(v[0], p.pro_slope); v[1] = ev_lrelu(v[1], p.pro_slope);
+            v[2] = ev_lrelu(v[2], p.pro_slope); v[3] = ev_lrelu(v[3], p.pro_slope);
+            uint2 q0v, q1v;
+            evh_split4(v * sx, q0v, q1v);
+            if (r < xrows) {
+                char* dst = Xb + r * RSB + sc4 * 2;
+                *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v;
+            }
+        }
+    }
+    const float u1 = pp.w1h_scale * sx;
+    acc_init(pp.b1, u1);
+    ev_lds_barrier();
+    kloop(rW1, tlv1, ng1, Xb + (wn * (TN * 32) + f16i + pp.h1) * RSB + 16 * kg);
+    ring_fill(rW2, tlv2, ng2);                           // c2's first fragments fly under the hand-over below
+
+    // ---------------- y1 = lrelu(c1 + b1), zero outside the utterance; its maximum over the workgroup -> sy; split into LDS rows r + h2
+    float sy;
+    {
+        const float inv1 = 1.0f / u1;
+        float my = 0.f;
+#pragma unroll
+        for (int b = 0; b < QN; ++b) {
+            const int r = wn * (TN * 32) + b * 16 + f16i;
+            const int n = g0 + r;
+            const int t = (n >= 0 && n < p.nrows) ? (n % p.S) - p.P : -1;
+            const float inside = (t >= 0 && t < p.T) ? inv1 : 0.f;
+#pragma unroll
+            for (int a = 0; a < QM; ++a)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = ev_lrelu(acc[a][b][e] * inside, pp.mid_slope);    // (back to true units; 0 outside the utterance)
+                    acc[a][b][e] = v;
+                    my = fmaxf(my, fabsf(v));
+                }
+        }
+        float tmy = wg_max(my, 4);                      // (the barrier inside: every wave is done reading the X tile)
+        if (!evh_is_finite(tmy)) {
+            my = 0.f;
+#pragma unroll
+            for (int a = 0; a < QM; ++a)
+#pragma unroll
+                for (int b = 0; b < QN; ++b) my = fmaxf(my, evh_absmax4_finite(acc[a][b]));
+            tmy = wg_max(my, 12);
+        }
+        sy = evh_scale_for(tmy);
+#pragma unroll
+        for (int b = 0; b < QN; ++b) {
+            const int r = wn * (TN * 32) + b * 16 + f16i;
+#pragma unroll
+            for (int a = 0; a < QM; ++a) {
+                uint2 q0v, q1v;
+                evh_split4(acc[a][b] * sy, q0v, q1v);
+                char* dst = Xb + (r + pp.h2) * RSB + (wm * 32 + a * 16 + 4 * kg) * 2;
+                *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v;
+            }
+        }
+        // the 2 h2 border rows only feed outputs outside the stored window, but must be finite: zero both planes
+        for (int i = tid; i < 2 * pp.h2 * (4 * C / 16); i += 256) {
+            const int br = i / (4 * C / 16), c16 = i % (4 * C / 16);
+            const int row = br < pp.h2 ? br : NT + br;
+            uint4 z = {0u, 0u, 0u, 0u};
+            *(uint4*)(Xb + row * RSB + c16 * 16) = z;
+        }
+    }
+    const float u2 = p.wh_scale * sy;
+    acc_init(p.bias, u2);
+    ev_lds_barrier();
+
+    // ---------------- phase 2: c2 over the LDS-resident y1 (tap offset t reads rows r + h2 + t)
+    kloop(rW2, tlv2, ng2, Xb + (wn * (TN * 32) + f16i + pp.h2) * RSB + 16 * kg);
+    {
+        const float inv2 = 1.0f / u2;
+#pragma unroll
+        for (int a = 0; a < QM; ++a)
+#pragma unroll
+            for (int b = 0; b < QN; ++b) acc[a][b] *= inv2;
+    }
+    conv_epilogue_lean_q<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
 }
 
 // ---------------------------------------------------------------------------

@@ -20,8 +20,11 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # Kernels one config-2 step launches (names from the rocprofv3 kernel trace of `bench.py --no-extras`, profiles/r03_bench_b64_kernel_stats.csv
 # and its round-4 successor; template arguments as the trace prints them).
 CONFIG2_LAUNCH_LIST = [
-    r"conv_h16_kernel<128, 128, 2, 2, 1>", r"conv_h16_kernel<128, 128, 2, 2, 3>", r"conv_h16_kernel<64, 128, 2, 2, 1>",
+    r"conv_h16_kernel<128, 128, 2, 2, 1, 1>", r"conv_h16_kernel<128, 128, 2, 2, 3, 1>", r"conv_h16_kernel<64, 128, 2, 2, 1, 1>",
+    r"conv_h16_kernel<128, 128, 2, 2, 1, 0>", r"conv_h16_kernel<128, 128, 2, 2, 3, 0>", r"conv_h16_kernel<64, 128, 2, 2, 1, 0>",
     r"ln_mlp_h16_kernel<0>", r"ln_qkv_h16_kernel<0>", r"conv_h16_bal_kernel<128, 128, 2, 2, 1, 9, 9>",
+    r"resblock_pair_h16q_kernel<2, 2, 1>", r"resblock_pair_h16q_kernel<1, 4, 1>", r"resblock_pair_h16q_kernel<4, 1, 1>",
+    r"resblock_pair_h16q_kernel<2, 2, 3>", r"resblock_pair_h16q_kernel<1, 4, 3>",
     r"resblock_pair_h16_kernel<2, 2, 1>", r"resblock_pair_h16_kernel<1, 4, 1>", r"resblock_pair_h16_kernel<4, 1, 1>",
     r"resblock_pair_h16_kernel<2, 2, 3>", r"resblock_pair_h16_kernel<1, 4, 3>",
     r"attn_out_kernel", r"groupnorm_mish_kernel<512, false>",

@@ -97,6 +97,16 @@ __global__ __launch_bounds__(256) void loop_kernel(const unsigned* W, float* out
     if (blockIdx.x == 0 && tid == 0) { clk[0] = __builtin_amdgcn_s_memtime() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
 }
 
+// layout check with exact data: lane l supplies A[row l % 16][k 8 (l / 16) .. + 7] and B[k 8 (l / 16) .. + 7][col l % 16]; D[row 4 (l / 16) + i][col l % 16] comes back in register i
+__global__ void layout_kernel(const float* A /*16 x 32*/, const float* B /*32 x 16*/, float* D /*16 x 16*/) {
+    const int l = threadIdx.x, r = l & 15, g = l >> 4;
+    f16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (_Float16)A[r * 32 + 8 * g + e]; b[e] = (_Float16)B[(8 * g + e) * 16 + r]; }
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    for (int i = 0; i < 4; ++i) D[(4 * g + i) * 16 + r] = c[i];
+}
+
 template <int SHAPE, int FED> static int run(const char* name, const unsigned* W, float* out, int wpc) {
     const int iters = 20000, grid = 256 * wpc;
     static unsigned long long* clk = nullptr;
@@ -126,6 +136,18 @@ int main() {
     for (auto& v : hw) { x = x * 1664525u + 1013904223u; unsigned h = x; h ^= h >> 15; h *= 2246822519u;
                          v = (((h & 1u) << 15) | ((10u + ((h >> 1) & 7u)) << 10) | ((h >> 4) & 1023u)) | (((((h >> 14) & 1u) << 15) | ((10u + ((h >> 15) & 7u)) << 10) | ((h >> 18) & 1023u)) << 16); }
     CHK(hipMemcpy(W, hw.data(), 2 << 20, hipMemcpyHostToDevice));
+    {
+        std::vector<float> A(16 * 32), B(32 * 16), D(256);
+        for (int i = 0; i < 16; ++i) for (int k = 0; k < 32; ++k) A[i * 32 + k] = (float)((i * 3 + k * 5) % 7 - 3);
+        for (int k = 0; k < 32; ++k) for (int j = 0; j < 16; ++j) B[k * 16 + j] = (float)((k * 2 + j * 3) % 5 - 2);
+        float *dA, *dB, *dD; CHK(hipMalloc(&dA, A.size() * 4)); CHK(hipMalloc(&dB, B.size() * 4)); CHK(hipMalloc(&dD, D.size() * 4));
+        CHK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CHK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(layout_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+        CHK(hipMemcpy(D.data(), dD, D.size() * 4, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) { float r = 0; for (int k = 0; k < 32; ++k) r += A[i * 32 + k] * B[k * 16 + j]; bad += (r != D[i * 16 + j]); }
+        printf("v_mfma_f32_16x16x32_f16 layout hypothesis (A row l%%16, k 8(l/16)..; D row 4(l/16)+i, col l%%16): %s (%d mismatches)\n", bad ? "WRONG" : "confirmed", bad);
+    }
     printf("fp16 MFMA shapes on random unit-scale data, 256 CUs, 20000 iterations per wave, 64 x 64 outputs per wave, 3 products of two pieces:\n");
     for (int rep = 0; rep < 2; ++rep)
         for (int w = 1; w <= 2; ++w) {

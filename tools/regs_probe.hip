@@ -30,3 +30,12 @@ template __global__ void conv_gemm_sk_kernel<4, false, 3, 4>(const ConvParams);
 template __global__ void conv_gemm_sk_kernel<4, false, 0, 4>(const ConvParams);
 template __global__ void conv_gemm_sk_kernel<4, true, 0, 4>(const ConvParams);
 template __global__ void conv_gemm_kernel<128, 192, 2, 2, false, true, 0, 1>(const ConvParams);
+// the 16 x 16 x 32 form of the deep vocoder convs (round 4)
+template __global__ void conv_h16_kernel<128, 128, 2, 2, 1, 1>(const ConvParams);
+template __global__ void conv_h16_kernel<128, 128, 2, 2, 3, 1>(const ConvParams);
+template __global__ void conv_h16_kernel<64, 128, 2, 2, 1, 1>(const ConvParams);
+template __global__ void resblock_pair_h16q_kernel<2, 2, 1>(const PairParams);
+template __global__ void resblock_pair_h16q_kernel<1, 4, 1>(const PairParams);
+template __global__ void resblock_pair_h16q_kernel<4, 1, 1>(const PairParams);
+template __global__ void resblock_pair_h16q_kernel<2, 2, 3>(const PairParams);
+template __global__ void resblock_pair_h16q_kernel<1, 4, 3>(const PairParams);
