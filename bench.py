@@ -39,7 +39,7 @@ PEAK_HBM_GBS = 8000.0
 # SURVEY.md §8(d), measured on the reference modules: FLOPs and layer-granular activation bytes per 6-s utterance
 ALG_FLOP_PER_AUDIO_S = 62.5e9
 ALG_BYTES_PER_AUDIO_S = 520e6
-TRAFFIC_JSON = ("profiles/r03_conv_hbm_traffic_pmc.json", "profiles/r02_conv_hbm_traffic_pmc.json", "profiles/r01_conv_hbm_traffic_pmc.json")
+TRAFFIC_JSON = ("profiles/r04_conv_hbm_traffic_pmc.json", "profiles/r03_conv_hbm_traffic_pmc.json", "profiles/r02_conv_hbm_traffic_pmc.json", "profiles/r01_conv_hbm_traffic_pmc.json")
 
 
 def log(*a):
@@ -397,9 +397,22 @@ def config5_record(model, voc, n_utt=32):
     cold, cold_frames = run(cold_texts)
     cold["new_lengths"] = int(sum(1 for f in cold_frames if f not in set(seen)))
     cold["allocs_during"] = int(model.engine.alloc_count() + voc.engine.alloc_count() - a0)
+    # the same warm texts with the CFM decode replayed from HIP graphs (MatchaTTS.enable_decode_graphs: one graph per padded length, captured
+    # on first use — the untimed pass below — then one hipGraphLaunch instead of ~700 launches per utterance)
+    graphs = None
+    try:
+        dg = model.enable_decode_graphs()
+        run(warm_texts)                                          # untimed: captures
+        torch.cuda.synchronize()
+        graphs, _ = run(warm_texts)
+        graphs.update({"graphs_captured": dg.captures, "replays": dg.hits, "eager_fallbacks": dg.fallbacks})
+    except Exception as ex:  # noqa: BLE001
+        log(f"[bench] config5 graph-replay pass skipped: {type(ex).__name__}: {ex}")
+    finally:
+        model.decode_graphs = None
     model.rng = rng_was
     return {"utterances": n_utt, "note": "B=1, length_scale 0.8, 10 Euler steps, temperature 0.667, HiFi-GAN + clamp + denoiser; handles reserved for 1200 frames; lengths ~ U{86..860} frames (SURVEY 8d)",
-            "warm": warm, "cold_length": cold}
+            "warm": warm, "cold_length": cold, "warm_graph_replay": graphs}
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -512,12 +525,17 @@ def main():
         log(f"[bench] warmup step {time.perf_counter() - tw:.3f} s")
     D.barrier()
     torch.cuda.synchronize()
+    sk_engines = [model.engine] + [m.engine for m in extra_models[0::2]]   # the decoders' handles: their balanced launches hand partial tiles over
+    sk0 = [e.sk_stats() for e in sk_engines]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full, wav, mel = step()
     torch.cuda.synchronize()
     D.barrier()
     dt = time.perf_counter() - t0
+    sk1 = [e.sk_stats() for e in sk_engines]
+    handoffs = {"balanced_launches": int(sum(b[0] - a[0] for a, b in zip(sk0, sk1))), "waits_ran_out": int(sum(b[2] - a[2] for a, b in zip(sk0, sk1))),
+                "note": "over the timed steps, all pipelines: launches of the balanced persistent builds and hand-off waits that ran out (the owner then recomputed the share itself)"}
     dt_rank = dt
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     per_rank_ms = [round(dt / args.steps * 1e3, 2)]
@@ -583,8 +601,14 @@ def main():
             try:
                 tj = json.load(open(os.path.join(REPO, tj_path)))
                 if B == 64 and T == 516 and n_ode == 10:
+                    import hashlib
+                    hsh = hashlib.sha256()
+                    for rel in ("emojivoice_amd/csrc/ev_kernels.h", "emojivoice_amd/csrc/ev_engine.hip", "include/emojivoice.h"):
+                        hsh.update(open(os.path.join(REPO, rel), "rb").read())
                     traffic = {"bytes_per_launch": round(tj["hbm_MB_per_launch"] * 1e6), "GB_per_step": round(tj["hbm_GB_per_step"], 1),
-                               "measured_in_this_run": False, "source": tj_path + " (builder's earlier rocprofv3 --pmc passes of this command)"}
+                               "measured_in_this_run": False, "source": tj_path + " (builder's earlier rocprofv3 --pmc passes of this command)",
+                               "pmc_library_source_sha16": tj.get("library_source_sha16"), "this_library_source_sha16": hsh.hexdigest()[:16],
+                               "same_library": tj.get("library_source_sha16") == hsh.hexdigest()[:16]}
                     break
             except Exception:
                 pass
@@ -727,7 +751,7 @@ def main():
             "per_gpu_audio_s_per_s": round(per_gpu, 2), "rtf": round(1.0 / per_gpu, 6), "x_realtime_per_gpu": round(per_gpu, 1),
             "serial_ms_per_step": round(serial_ms, 2), "batch_latency_ms": round(batch_latency_ms, 2), "stage_ms": stage_ms,
             "text_encoder": text_enc,
-            "value_fp32_mfma": fp32,
+            "value_fp32_mfma": fp32, "balanced_handoffs": handoffs,
             "roofline": roofline, "path_roofline": path_roof, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "config4": c4, "config5": c5, "arithmetic_settings": arith,
         }

@@ -23,7 +23,7 @@ EXPORTS = [
     "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read", "ev_profile_read_split", "ev_dbg_last_cfg", "ev_set_arithmetic", "ev_get_arithmetic",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_split_pieces", "ev_op_attention", "ev_op_ln_mlp", "ev_set_mrf_streams_max",
-    "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out",
+    "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out", "ev_dbg_set_amax",
 ]
 
 
@@ -101,6 +101,7 @@ def load_library() -> C.CDLL:
     lib.ev_dbg_last_cfg.argtypes = [vp]
     lib.ev_set_arithmetic.argtypes = [vp, i32]
     lib.ev_get_arithmetic.argtypes = [vp]
+    lib.ev_dbg_set_amax.argtypes = [vp, i32]
     lib.ev_op_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
     lib.ev_op_groupnorm_mish.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ev_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
@@ -342,6 +343,10 @@ class Engine:
         three fp16 products per fp32 product (22-23 significand bits, fp32 accumulation); 6: three bf16 pieces, six exact products;
         0: every product on the exact fp32 MFMA (v_mfma_f32_32x32x2_f32); 3: opt-in fast bf16 setting, NOT fp32-grade; 9: A/B."""
         self._check(self.lib.ev_set_arithmetic(self.h, int(bf16_products)), "ev_set_arithmetic")
+
+    def set_amax(self, on: bool) -> None:
+        """True (default): the fp16 builds take their tile scales from the producers' amax slots; False: every tile pre-scans (ev_dbg_set_amax)."""
+        self._check(self.lib.ev_dbg_set_amax(self.h, int(bool(on))), "ev_dbg_set_amax")
 
     def arithmetic(self) -> int:
         return int(self.lib.ev_get_arithmetic(self.h))

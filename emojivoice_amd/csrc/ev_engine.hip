@@ -60,6 +60,9 @@ struct Epi {
     float* gn_part = nullptr;               // ask for the per-tile GroupNorm statistics of the output (conv_sk32_kernel, one utterance); whether
                                             // they were produced is left in ev_handle::gn_stats_tiles (0 = no)
     int isplit_log2 = 31, isstride = 0;     // input column split (pair view of a strided slice)
+    // amax slots (ConvParams::ymax / rmax / xmax, ev_kernels.h "Tile maxima from the producer"): ev_hifigan passes the slots of the tensors a launch
+    // writes / adds / reads; a launch whose build does not leave bounds reports so in ev_handle::amax_emitted
+    unsigned* ymax = nullptr; int ymax_mul = 1; const unsigned* rmax = nullptr; const unsigned* yold = nullptr; const unsigned* xmax = nullptr; int xmax_n = 0;
     int osplit_log2 = 31, osstride = 0;     // output column split
 };
 
@@ -137,7 +140,14 @@ struct ev_handle {
     float* temb_host[2] = {nullptr, nullptr}; size_t temb_cap[2] = {0, 0}; hipEvent_t temb_ev[2] = {nullptr, nullptr}; int temb_slot = 0;
     // Captured ev_cfm_decode calls stage their time embeddings in pinned memory that is NEVER recycled (a replay reads it whenever
     // the graph runs): EV_CAPTURE_SLOTS regions of one block allocated by ev_load_estimator, one consumed per captured call.
-    float* cap_pool = nullptr; size_t cap_stride = 0; int cap_used = 0;
+    float* cap_pool = nullptr; size_t cap_stride = 0; int cap_used = 0; int cap_nt[8] = {0};   // (cap_nt: the step count each region holds the time grid of)
+    // The time MLP's output for a decode of n Euler steps (sinusoid -> linear_1 -> SiLU -> linear_2 -> Mish -> the six resnet projections:
+    // n x 1536 floats) depends on n and the weights only — the time grid of solve_euler is torch.linspace(0, 1, n + 1) — so it is computed
+    // once per step count and kept in device memory of the handle (at most 8 step counts, then the oldest goes).  Every later decode with
+    // that n, eager or captured, reads it in place: four launches and one host-to-device copy fewer per decode, and — what made it
+    // necessary — no copy node in a captured decode (see cfm_decode_impl).
+    struct TprojEntry { int nt; float* d; };
+    std::vector<TprojEntry> tproj_cache;
     bool captured = false; int cap_B = 0, cap_Tp = 0;   // a handle with a captured call stays bound to that (B, Tp): see ev_cfm_decode
     int64_t n_allocs = 0;       // device / pinned allocations made by the hot calls after loading (workspace and scratch growth, staging)
     double prof_flops = 0; int64_t prof_launches = 0;
@@ -155,6 +165,8 @@ struct ev_handle {
     int split_terms = 16;           // arithmetic of the deep layers' products (ev_set_arithmetic; EV_SPLIT presets it): 16 = shipped: two block-scaled
                                     // fp16 pieces per operand, three products (fp32-grade); 6 = three bf16 pieces, six products (fp32-grade, no
                                     // range handling needed); 0 = fp32 MFMA everywhere; 3 = opt-in fast bf16 setting (not fp32-grade); 9 = A/B
+    bool use_amax = true;           // EV_NO_AMAX=1 / ev_dbg_set_amax(h, 0): every fp16 tile pre-scans its input (A/B runs, tests of that path)
+    bool amax_emitted = false;      // set by every launch_conv / launch_pair: the launch left per-granule bounds of its output in Epi::ymax
     int n_fp32_only_layers = 0;     // layers whose weights are not the exact sum of three bf16 pieces (tiny or non-finite): they keep the fp32 MFMA build
     int last_cfg = -1;              // build the last launch_conv / launch_pair took (ev_dbg_last_cfg: tests assert that a shape ran on the build they mean)
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
@@ -670,6 +682,10 @@ int launch_h16_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
         HIPCHK(h, hipMemsetAsync(d, 0, (size_t)G * 16 * sizeof(unsigned long long), h->stream));
         p.stamps = d;
     }
+    {   // A/B: start stagger of the second workgroup of every CU, in steps of ~1 us (conv_h16_bal_kernel)
+        static const int stag = getenv("EV_BAL_STAGGER") ? atoi(getenv("EV_BAL_STAGGER")) : 0;
+        p.stagger_slots = (wpc == 2) ? stag : 0;
+    }
     const bool narrow = BN + p.halo_lo + p.halo_hi <= 16 * 9;         // a 3-tap layer: nine staging passes instead of twelve
     if (lean_acc(p)) {
         if (narrow) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 3, 9>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 3, 9>), dim3(G), dim3(256), smem, h->stream, p); }
@@ -749,6 +765,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     p.mask1 = e.mask1; p.scale = e.scale; p.R = e.R; p.ldr = e.ldr; p.accum = e.accum; p.div3 = e.div3;
     p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope; p.mask2 = e.mask2; p.rowmask = e.rowmask;
     p.Y2 = e.Y2; p.ldy2 = e.ldy2; p.dbg = e.dbg; p.stamps = e.stamps;
+    p.xmax = e.xmax; p.xmax_n = e.xmax_n; p.rmax = e.rmax; p.yold = e.yold; p.ymax_mul = e.ymax_mul; h->amax_emitted = false;   // (p.ymax: set below, once the build is known)
     if ((ldx & 3) || (L.Cin & 3)) return fail(h, "conv input must be float4-aligned (ldx %d Cin %d)", ldx, L.Cin);
     {   // buffer (SRSRC) addressing uses 32-bit byte offsets: every tensor of a launch must stay below 4 GiB
         const double lim = 4294967296.0;
@@ -854,6 +871,15 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     }
     if ((cfg == 40 || cfg == 41 || cfg == 43 || cfg == 46 || cfg == 49 || cfg == 60) && !split_ok(L, p)) cfg = 0;
     if (cfg == 46 && !L.Wh) cfg = 40;
+    {   // which builds leave bounds of their output: the fp16 builds 46 / 47 (cfg 41 becomes 47 below when the layer has fp16 pieces) and the
+        // fp32 conv_gemm_kernel tiles with the lean non-SnakeBeta epilogues; a residual without slots of its own cannot be bounded
+        const bool lean1or3 = lean_ok(p) && p.act != ACT_SNAKE && !getenv("EV_NO_LEAN");
+        const bool h16 = (cfg == 46) || (cfg == 41 && h->split_terms == 16 && L.Wh);
+        const bool gemm = (cfg == 0 || cfg == 1 || cfg == 5 || cfg == 6) && lean1or3 && lo.kb == 1;
+        const bool no_amax = !h->use_amax;                                          // A/B: every fp16 tile pre-scans
+        if (!no_amax && e.ymax && lean1or3 && (h16 || gemm) && (!e.R || e.rmax) && (!e.accum || e.yold)) { p.ymax = e.ymax; h->amax_emitted = true; }
+        if (no_amax) p.xmax = nullptr;
+    }
     if (cfg == 46) {   // 128 x 128 on the fp16 pipe, two block-scaled pieces, three products
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         launch_h16<128, 128, 2, 2>(p, h->stream, lo);
@@ -883,6 +909,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     } else if (cfg == 5) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 191) / 192; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         static const int bal5 = getenv("EV_BAL5") ? atoi(getenv("EV_BAL5")) : 0;      // A/B: 0 = as is, 192 = balanced 64 x 192, 64 = balanced 64 x 64
+        if (bal5 != 0) { p.ymax = nullptr; h->amax_emitted = false; }
         if (bal5 == 192 && lo.kb == 1 && bal_ok(h, L, p, (long)p.mtiles * p.ntiles, 3)) { if (launch_bal<64, 192, 2, 2>(h, p, lo, 3)) return 1; cfg = 55; }
         else if (bal5 == 64 && lo.kb == 1 && bal_ok(h, L, p, (long)((L.Cout + 63) / 64) * ((g.nrows + 63) / 64), 4)) {
             p.ntiles = (g.nrows + 63) / 64;
@@ -925,6 +952,7 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     } else if (cfg == 6) {
         p.mtiles = (L.Cout + 63) / 64; p.ntiles = (g.nrows + 63) / 64; p.taplist = L.taplist[1]; p.nact_tab = L.nact[1]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         if (lo.kb == 1 && bal_ok(h, L, p, (long)p.mtiles * p.ntiles, 4)) {
+            p.ymax = nullptr; h->amax_emitted = false;          // (the balanced build leaves no bounds)
             unsigned long long wtab = 0;
             if (L.sparse_taps) for (int t = 0; t < p.mtiles; ++t) wtab |= (unsigned long long)L.nact64[t] << (4 * t);
             if (launch_bal<64, 64, 2, 2>(h, p, lo, 4, wtab)) return 1;
@@ -979,6 +1007,7 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     p.scale = 1.f; p.R = X; p.ldr = C; p.accum = e.accum; p.div3 = e.div3; p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope;
     pp.W1 = L1.W; pp.W1x = L1.Wx; p.Wx = L2.Wx; pp.W1h = L1.Wh; pp.w1h_scale = L1.wh_scale; p.Wh = L2.Wh; p.wh_scale = L2.wh_scale; pp.W1q = L1.Wq; p.Wq = L2.Wq; pp.b1 = L1.bias; pp.taplist1 = L1.taplist[0]; pp.ntaps1 = L1.ntaps;
     pp.h1 = L1.halo_lo; pp.h2 = L2.halo_lo; pp.mid_slope = 0.1f;
+    p.rmax = nullptr; p.yold = e.yold; p.ymax_mul = 1; h->amax_emitted = false;   // (R = X: the fp16 pair kernels bound the residual by their own tile maximum; p.ymax below)
     if ((double)g.nrows * C * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
     if (L1.sparse_taps || L2.sparse_taps || L1.Kpad != C || L2.Kpad != C || L1.Kpad != L2.Kpad || L1.Mpad != L2.Mpad || L1.halo_lo != L1.halo_hi ||
         L2.halo_lo != L2.halo_hi || 2 * pp.h2 > 16 || !L1.bias || !L2.bias)
@@ -997,13 +1026,17 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     const bool split = split_terms > 0 && lean != 0 && L1.Wx && L2.Wx && !(e.force_cfg == 0);
     const bool h16 = split && split_terms == 16 && L1.Wh && L2.Wh;
     if (h16) {   // the fp16 build: two block-scaled fp16 planes per LDS row
+        if (e.ymax && (!e.accum || e.yold) && h->use_amax) { p.ymax = e.ymax; h->amax_emitted = true; }   // (the residual's bound: the pair's own tile maximum)
         const int NT = C == 32 ? 256 : C == 64 ? 128 : 64, RSB = 4 * C + 16;
         if (C != 32 && C != 64 && C != 128) return fail(h, "launch_pair: C must be 32, 64 or 128");
         pp.out_rows = NT - 2 * pp.h2; p.mtiles = 1; p.ntiles = (g.nrows + pp.out_rows - 1) / pp.out_rows;
         const size_t smem = std::max((size_t)(NT + EV_HALO) * RSB + 64, (size_t)4 * 32 * 36 * sizeof(float));   // (+ 16 floats: the waves' maxima)
         const dim3 grid(p.ntiles);
-        // both K loops on v_mfma_f32_16x16x32_f16 (resblock_pair_h16q_kernel) wherever the layers carry that fragment order; EV_H16Q=0: the 32 x 32 x 16 form (A/B)
-        static const bool use_q = !(getenv("EV_H16Q") && atoi(getenv("EV_H16Q")) == 0);
+        // EV_PAIR_Q=1: both K loops on v_mfma_f32_16x16x32_f16 (resblock_pair_h16q_kernel).  Measured null, not the default: same box, config 2 —
+        // every pair shape within 1 % of the 32 x 32 x 16 form (C = 128 k3 3 % slower: 150 registers admit three workgroups per CU instead of four),
+        // while conv_h16_kernel gains 3-9 % from the same change (profiles/r04_mfma_shape_ab.txt): the pairs' K loops are too short (C <= 128 deep)
+        // for the MFMA phase to be what the power limit throttles.
+        static const bool use_q = getenv("EV_PAIR_Q") && atoi(getenv("EV_PAIR_Q")) != 0;
         const bool q = use_q && L1.Wq && L2.Wq;
 #define EV_PAIR_H16(WM, WN) do { \
             if (q && lean == 1) { ensure_dyn_smem<resblock_pair_h16q_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_pair_h16q_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, pp); } \
@@ -1461,7 +1494,10 @@ struct VocBufs {
     float *M0, *C0;
     float *U[5], *XS[5], *T1[5], *Pa[5], *Pb[5];
     float *T1x[2][5], *Pax[2][5], *Pbx[2][5];   // scratch of the second and third ResBlock1 chain (three-stream MRF; null otherwise)
-    struct { float* p; int C, l; } zl[64]; int nz = 0;   // every tensor of the plan (for zero_pads_kernel)
+    struct { float* p; int C, l; unsigned* amax[2]; int amax_n; } zl[64]; int nz = 0;   // every tensor of the plan (for zero_pads_kernel) and its two sets of amax slots
+    unsigned* slots = nullptr; size_t slot_words = 0;    // one block behind the tensors: per tensor 2 x ((rows >> 7) + 2) words, zeroed by every ev_hifigan call
+    // slots of a tensor of this plan (null: not one of them)
+    int index_of(const float* q) const { for (int k = 0; k < nz; ++k) if (zl[k].p == q) return k; return -1; }
 };
 
 void plan_voc(Bump& b, int B, int T, const int* ch, VocBufs& v, bool mrf_streams = false) {
@@ -1484,6 +1520,12 @@ void plan_voc(Bump& b, int B, int T, const int* ch, VocBufs& v, bool mrf_streams
             v.Pbx[c][l] = mrf_streams ? take(n, ch[l], l) : nullptr;
         }
     }
+    v.slot_words = 0;
+    for (int k = 0; k < v.nz; ++k) { v.zl[k].amax_n = (v.g[v.zl[k].l].nrows >> 7) + 2; v.slot_words += 2 * (size_t)v.zl[k].amax_n; }
+    v.slots = (unsigned*)b.take(v.slot_words);
+    size_t off = 0;
+    for (int k = 0; k < v.nz; ++k)
+        for (int c = 0; c < 2; ++c) { v.zl[k].amax[c] = v.slots ? v.slots + off : nullptr; off += (size_t)v.zl[k].amax_n; }
 }
 inline bool mrf_streams_for(const ev_handle* h, int B, int Tv) { return h->mrf_max_frames > 0 && (long)B * Tv <= h->mrf_max_frames; }
 
@@ -1543,7 +1585,15 @@ int ensure_ws(ev_handle* h, int B, int Tp, int Tv, EstBufs* eb, VocBufs* vb) {
         // the pad rows, which is all the convolutions need (zero_pads_kernel)
         static const bool full_zero = getenv("EV_FULL_REZERO") != nullptr;
         const size_t zbytes = (full_zero || Tv <= 0) ? need : voc_off;
-        if (zbytes) HIPCHK(h, hipMemsetAsync(h->ws, 0, zbytes, h->stream));
+        if (zbytes) {
+            hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+            const bool capturing = h->stream && hipStreamIsCapturing(h->stream, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive;
+            if (capturing || h->captured) {      // (kernel nodes only in a captured call — and the same path for the eager calls of a handle that holds graphs)
+                const size_t n16 = (zbytes + 15) / 16;
+                hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 2048)), dim3(256), 0, h->stream, (f32x4*)h->ws, n16);
+                HIPCHK(h, hipGetLastError());
+            } else HIPCHK(h, hipMemsetAsync(h->ws, 0, zbytes, h->stream));
+        }
         if (!full_zero && Tv > 0 && vplan.nz > 0) {
             ZeroPadParams zp;
             memset(&zp, 0, sizeof zp);
@@ -1616,12 +1666,12 @@ int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z,
 }
 
 // One estimator evaluation.  euler: state += dt * v, X0[:, :80] = state * m ; else V0 = v.
-int run_estimator(ev_handle* h, EstBufs& b, int step, float dt, bool euler) {
+int run_estimator(ev_handle* h, EstBufs& b, int step, float dt, bool euler, const float* tproj = nullptr) {
     const EstimatorW& w = h->est;
     const int heads = h->dims.heads;
     LevelBufs L0{b.A0, b.B0, b.R0, b.H0, b.LN0, b.QKV0, b.ATT0, b.FF0, b.rm0, b.g0, b.AR0, b.ATTP, b.GNP};
     LevelBufs L1{b.A1, b.B1, b.R1, b.H1, b.LN1, b.QKV1, b.ATT1, b.FF1, b.rm1, b.g1, b.AR1, b.ATTP, b.GNP};
-    const float* tp = b.tproj + (size_t)step * 1536;
+    const float* tp = (tproj ? tproj : b.tproj) + (size_t)step * 1536;
     // down 0 @T
     if (run_resnet0(h, w, b.X0, w.in_ch, L0, tp + 0 * 256, b.C1RMS)) return 1;
     if (run_transformer(h, w.tr[0], L0, b.CAT1 + 256, 512, heads)) return 1;      // hidden 0
@@ -1685,10 +1735,17 @@ int run_time_mlp(ev_handle* h, EstBufs& b, const std::vector<float>& ts) {
         const float* src = nullptr;
         if (capturing) {
             if (!h->cap_pool || bytes > h->cap_stride) return fail(h, "ev_cfm_decode under stream capture: %d Euler steps exceed the capture staging (%zu bytes per call)", nt, h->cap_stride);
-            if (h->cap_used >= EV_CAPTURE_SLOTS) return fail(h, "ev_cfm_decode under stream capture: this handle has already captured %d calls (their staging is never recycled)", EV_CAPTURE_SLOTS);
-            float* dst = (float*)((char*)h->cap_pool + (size_t)h->cap_used++ * h->cap_stride);
-            memcpy(dst, emb.data(), bytes);
-            src = dst;
+            // the time grid depends on the number of Euler steps only (flow_matching.py:52): captured calls with the same step count share
+            // ONE region (written once, never again), so the pool bounds the distinct step counts a handle captures, not the number of graphs
+            int slot = -1;
+            for (int k = 0; k < h->cap_used; ++k) if (h->cap_nt[k] == nt) slot = k;
+            if (slot < 0) {
+                if (h->cap_used >= EV_CAPTURE_SLOTS) return fail(h, "ev_cfm_decode under stream capture: this handle has already captured calls with %d different step counts (their staging is never recycled)", EV_CAPTURE_SLOTS);
+                slot = h->cap_used++;
+                h->cap_nt[slot] = nt;
+                memcpy((char*)h->cap_pool + (size_t)slot * h->cap_stride, emb.data(), bytes);
+            }
+            src = (const float*)((const char*)h->cap_pool + (size_t)slot * h->cap_stride);
         } else {
             const int slot = (h->temb_slot ^= 1);
             if (h->temb_cap[slot] < bytes) {
@@ -1938,6 +1995,7 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     { const char* fp = getenv("EV_FUSE_ATTN"); if (fp && *fp == '0') h->fuse_attn = false; }
     { const char* fp = getenv("EV_FUSE_MLP_MIN"); if (fp && *fp) h->fuse_mlp_min_tiles = atoi(fp); }
     { const char* fp = getenv("EV_MRF_STREAMS_MAX"); if (fp && *fp) h->mrf_max_frames = atoi(fp); }
+    if (getenv("EV_NO_AMAX")) h->use_amax = false;
     { const char* sp = getenv("EV_SPLIT"); if (sp && *sp) { const int t = atoi(sp); h->split_terms = (t == 0 || t == 3 || t == 6 || t == 9 || t == 16) ? t : 16; } }
     { const char* fp = getenv("EV_NO_SK_BALANCE"); if (fp && *fp && *fp != '0') h->sk_balance = false; }
     { const char* fp = getenv("EV_SK_SPIN"); if (fp && *fp) h->sk_spin = atoi(fp); }
@@ -1961,6 +2019,8 @@ void ev_destroy(ev_handle* h) {
     for (void* p : h->owned) hipFree(p);
     if (h->ws) hipFree(h->ws);
     if (h->cap_pool) hipHostFree(h->cap_pool);
+    for (auto& c : h->tproj_cache) hipFree(c.d);
+    h->tproj_cache.clear();
     if (h->sk_ctrl) hipFree(h->sk_ctrl);
     if (h->sk_part) hipFree(h->sk_part);
     for (hipEvent_t e : h->ev_pool) hipEventDestroy(e);
@@ -1994,6 +2054,11 @@ int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* in
     TensorMap m;
     if (build_map(h, blob, index, n, m)) return 1;
     if (ensure_sk(h, false)) return 1;
+    if (!h->tproj_cache.empty()) {                       // new weights: the cached time-MLP outputs are those of the old ones
+        HIPCHK(h, hipDeviceSynchronize());
+        for (auto& c : h->tproj_cache) hipFree(c.d);
+        h->tproj_cache.clear();
+    }
     EstimatorW& w = h->est;
     w.loaded = false;
 #define T_(k) find(h, m, k)
@@ -2286,10 +2351,11 @@ static int cfm_decode_impl(ev_handle* h, const float* d_mu, const int32_t* d_len
     h->stream = (hipStream_t)stream;
     hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
     const bool capturing = h->stream && hipStreamIsCapturing(h->stream, &cst) == hipSuccess && cst == hipStreamCaptureStatusActive;
-    // A captured call's kernels address the workspace as planned for its (B, Tp): from then on the handle only accepts that shape
-    // (another shape would re-plan and re-zero the arena under the graph), and nothing that would replace the arena.
-    if (h->captured && (B != h->cap_B || Tp != h->cap_Tp))
-        return fail(h, "this handle holds a captured ev_cfm_decode at (B=%d, Tp=%d): calls at (B=%d, Tp=%d) need another handle", h->cap_B, h->cap_Tp, B, Tp);
+    // A captured call's kernels address the workspace as planned for its (B, Tp).  The handle may hold captured calls of SEVERAL shapes
+    // (a serving loop keeps one graph per utterance length, emojivoice_amd.matcha_tts.DecodeGraphs) and serve eager calls of any shape
+    // in between: every call — captured or eager — of a handle that holds graphs starts by re-zeroing the estimator's part of the
+    // arena for its own plan (below), so no call depends on what an earlier one left in the pad rows.  What stays forbidden is anything
+    // that would REPLACE the arena (growth beyond the reservation, more Euler steps than planned): the graphs address it.
     if (n_steps > h->max_steps) {
         // the reference has no upper limit on n_timesteps: the per-step time-embedding buffers are re-planned when a call asks for more
         if (h->captured || capturing) return fail(h, "n_steps %d exceeds the %d the workspace is planned for and the handle is captured / capturing: call once eagerly first", n_steps, h->max_steps);
@@ -2297,10 +2363,12 @@ static int cfm_decode_impl(ev_handle* h, const float* d_mu, const int32_t* d_len
         h->ws_B = -1;
     }
     if (capturing) {
-        if (B != h->ws_B || Tp != h->ws_Tp || plan_all(h, nullptr, B, Tp, h->ws_Tv > 0 ? h->ws_Tv : 0, nullptr, nullptr) > h->ws_bytes)
-            return fail(h, "ev_cfm_decode under stream capture needs a prior eager call at (B=%d, Tp=%d) on this handle (workspace planning allocates and zeroes)", B, Tp);
+        if (plan_all(h, nullptr, B, Tp, 0, nullptr, nullptr) > h->ws_bytes)
+            return fail(h, "ev_cfm_decode under stream capture at (B=%d, Tp=%d) needs a workspace that is already large enough: ev_reserve (or one eager call at "
+                           "the largest shape) first — planning must not allocate under capture", B, Tp);
         h->captured = true; h->cap_B = B; h->cap_Tp = Tp;
     }
+    if (h->captured) h->ws_B = -1;          // (forces the re-zero of this call's plan: a memset + nothing else, capturable)
     EstBufs b;
     if (ensure_ws(h, B, Tp, 0, &b, nullptr)) return 1;
     // time grid exactly as torch.linspace(0, 1, n+1) + the running t / dt of solve_euler (flow_matching.py:52,70-83), in fp32
@@ -2321,9 +2389,37 @@ static int cfm_decode_impl(ev_handle* h, const float* d_mu, const int32_t* d_len
         }
     }
     if (prep_inputs(h, b, d_z, d_mu, d_lengths, d_spk, B, Tp)) return 1;
-    if (run_time_mlp(h, b, ts)) return 1;
+    // the time MLP's output for this step count: from the handle's cache, or computed now and cached for the next call.  A CAPTURED call
+    // must find it there: a host-to-device copy captured from pinned memory replays from a staging buffer of the HIP runtime that later
+    // eager copies recycle (measured: the second eager decode after a capture corrupts every later replay, tools/graph_debug2.py,
+    // profiles/r04_graph_capture_h2d_hazard.txt) — so a captured decode contains kernels and one memset, nothing else.
+    const float* tproj = nullptr;
+    for (auto& c : h->tproj_cache) if (c.nt == n_steps) tproj = c.d;
+    if (!tproj) {
+        if (capturing) return fail(h, "ev_cfm_decode under stream capture: no eager decode with %d Euler steps has run on this handle yet (the time embeddings of a "
+                                      "captured call must already be on the device: call once eagerly with this step count first)", n_steps);
+        if (run_time_mlp(h, b, ts)) return 1;
+        // keep it for the next decode with this step count: at most 8 step counts; a handle that holds graphs never drops an entry (a graph may
+        // address it) and simply stops caching new ones, any other handle drops its oldest
+        const size_t bytes = (size_t)n_steps * 1536 * sizeof(float);
+        bool room = h->tproj_cache.size() < 8;
+        if (!room && !h->captured) {
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            hipFree(h->tproj_cache.front().d);
+            h->tproj_cache.erase(h->tproj_cache.begin());
+            room = true;
+        }
+        float* d = nullptr;
+        if (room && n_steps <= 4096) {
+            if (hipMalloc((void**)&d, bytes) == hipSuccess) {
+                ++h->n_allocs;
+                HIPCHK(h, hipMemcpyAsync(d, b.tproj, bytes, hipMemcpyDeviceToDevice, h->stream));
+                h->tproj_cache.push_back({n_steps, d});
+            } else (void)hipGetLastError();
+        }
+    }
     for (int s = 0; s < n_steps; ++s)
-        if (run_estimator(h, b, s, dts[s], true)) return 1;
+        if (run_estimator(h, b, s, dts[s], true, tproj)) return 1;
     dim3 grid((Tp + 31) / 32, (80 + 31) / 32, B);
     if (d_dec) hipLaunchKernelGGL(fm_to_cm_kernel, grid, dim3(256), 0, h->stream, (const float*)b.state, 80, 0, d_dec, 80, Tp, b.g0.S, b.g0.P, 1.0f, 0.0f);
     if (d_out) hipLaunchKernelGGL(fm_to_cm_kernel, grid, dim3(256), 0, h->stream, (const float*)b.state, 80, 0, d_out, 80, Tp, b.g0.S, b.g0.P, out_scale, out_shift);
@@ -2459,9 +2555,34 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
     dim3 grid((T + 31) / 32, (80 + 31) / 32, B);
     hipLaunchKernelGGL(cm_to_fm_kernel, grid, dim3(256), 0, h->stream, d_mel, v.M0, 80, 0, 80, T, v.g[0].S, v.g[0].P, (const float*)nullptr, 1.0f);
     HIPCHK(h, hipGetLastError());
+    // amax slots: every tensor of the plan has per-128-row bounds of what this call stores in it (ev_kernels.h, "Tile maxima from the producer");
+    // zeroed here, left by each producer, read by the fp16 builds in place of their pre-scan.  `has[k]`: tensor k's slots hold bounds of its
+    // present contents (false until a build that leaves them has written it, and again after one that does not).
+    // Every tensor has TWO sets of slots and `cur[k]` says which one describes it: a launch that adds to a running sum (accum) reads the old
+    // bound from the current set and leaves the new one in the OTHER set, then the sets swap — a bound read from slots the same launch is
+    // updating would depend on timing, and the tile scales (hence the bits of the result) with it.
+    bool has[64] = {false};
+    int cur[64] = {0};
+    if (v.slots) HIPCHK(h, hipMemsetAsync(v.slots, 0, v.slot_words * sizeof(unsigned), h->stream));
+    auto with_slots = [&](Epi& e, const float* x, const float* r, float* y, int ymul) {   // before a launch
+        const int ix = v.index_of(x), ir = r ? v.index_of(r) : -1, iy = v.index_of(y);
+        if (!v.slots) return;
+        if (ix >= 0 && has[ix]) { e.xmax = v.zl[ix].amax[cur[ix]]; e.xmax_n = v.zl[ix].amax_n; }
+        if (ir >= 0 && has[ir]) e.rmax = v.zl[ir].amax[cur[ir]];
+        if (iy >= 0 && !e.accum) { e.ymax = v.zl[iy].amax[cur[iy]]; e.ymax_mul = ymul; }
+        if (iy >= 0 && e.accum && has[iy]) { e.yold = v.zl[iy].amax[cur[iy]]; e.ymax = v.zl[iy].amax[cur[iy] ^ 1]; e.ymax_mul = ymul; }
+    };
+    auto wrote = [&](float* y, bool accum) {                  // after it
+        const int iy = v.index_of(y);
+        if (iy < 0) return;
+        has[iy] = h->amax_emitted;
+        if (accum && h->amax_emitted) cur[iy] ^= 1;
+    };
     {   // conv_pre, with the first leaky_relu (models.py:184) fused as the epilogue: only ups[0] consumes it
         Epi e; e.act = ACT_LRELU; e.act_slope = 0.1f;
+        with_slots(e, v.M0, nullptr, v.C0, 1);
         if (launch_conv(h, w.pre, v.M0, 80, v.C0, w.ch[0], v.g[0], e)) return 1;
+        wrote(v.C0, false);
     }
     const float* xin = v.C0;
     int cin = w.ch[0];
@@ -2494,7 +2615,9 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
         const int l = i + 1, C = w.ch[l], s = w.ups[i].Cout / C;
         {   // transposed conv: input frames of level l-1 -> view rows of s output frames each
             Epi e;
+            with_slots(e, xin, nullptr, v.U[l], s);         // (a row of this launch = s rows of U[l]'s axis)
             if (launch_conv(h, w.ups[i], xin, cin, v.U[l], s * C, v.g[l - 1], e)) return 1;
+            wrote(v.U[l], false);
         }
         if (ms) {
             HIPCHK(h, hipEventRecord(h->mrf_ev[3], s0));
@@ -2517,11 +2640,20 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
                 }
                 if (h->fuse_pairs && (C == 32 || C == 64 || (C == 128 && h->fuse128 && w.c1[i * 3 + j][mm].ntaps <= h->fuse128))) {
                     // narrow stages: both convs of the pair in one launch, intermediate kept in LDS
+                    // (a fused pair finds its own tile maximum and bounds its residual with it: it needs no slots of x, and only the pair that
+                    // closes a chain into the running sum of a level whose sum an fp16 build consumes — the upsampler of levels 1..3 — leaves
+                    // bounds at all: an atomic per wave costs the narrow pairs 3-10 %, profiles/r04_amax_ab.txt)
+                    if (mm == 2 && l < 4) with_slots(e2, x, nullptr, y, 1);
                     if (launch_pair(h, w.c1[i * 3 + j][mm], w.c2[i * 3 + j][mm], x, y, C, v.g[l], e2)) return 1;
+                    wrote(y, e2.accum != 0);
                 } else {
                     Epi e1; e1.pro_slope = 0.1f; e1.act = ACT_LRELU; e1.act_slope = 0.1f;   // lrelu -> c1 -> lrelu
+                    with_slots(e1, x, nullptr, t1, 1);
                     if (launch_conv(h, w.c1[i * 3 + j][mm], x, C, t1, C, v.g[l], e1)) return 1;
+                    wrote(t1, false);
+                    with_slots(e2, t1, x, y, 1);
                     if (launch_conv(h, w.c2[i * 3 + j][mm], t1, C, y, C, v.g[l], e2)) return 1;
+                    wrote(y, e2.accum != 0);
                 }
                 if (ms && mm == 2) HIPCHK(h, hipEventRecord(h->mrf_ev[j], h->stream));
                 x = y;
@@ -2609,6 +2741,13 @@ int ev_set_arithmetic(ev_handle* h, int bf16_products) {
     return 0;
 }
 int ev_get_arithmetic(ev_handle* h) { return h ? h->split_terms : -1; }
+
+// Diagnostic / A-B switch (ABI v4): 1 (default) = the fp16 builds take their tile scales from the producers' amax slots, 0 = they pre-scan
+int ev_dbg_set_amax(ev_handle* h, int on) {
+    if (!h) return 1;
+    h->use_amax = on != 0;
+    return 0;
+}
 
 // The launches of the bf16-split builds (conv_split_kernel, conv_split_bal_kernel, resblock_pair_split_kernel) among those recorded
 // since the last reset: call before ev_profile_read(..., reset = 1).
@@ -2737,6 +2876,7 @@ int ev_op_conv1d(ev_handle* h, const float* d_x, const float* w, const float* bi
     P = 32;
     int rc = 0;
     float *X = nullptr, *Y = nullptr;
+    unsigned* XM = nullptr;
     do {
         Geom gin{B * (T + 2 * P), T + 2 * P, P, T};
         const int Pout = transposed ? P * stride : P / vf;
@@ -2748,6 +2888,13 @@ int ev_op_conv1d(ev_handle* h, const float* d_x, const float* w, const float* bi
         dim3 g1((T + 31) / 32, (Cin + 31) / 32, B);
         hipLaunchKernelGGL(cm_to_fm_kernel, g1, dim3(256), 0, h->stream, d_x, X, Cin, 0, Cin, T, gin.S, gin.P, (const float*)nullptr, 1.0f);
         Epi e; e.pro_slope = pre_lrelu_slope;
+        if (h->use_amax && !(!transposed && stride == 2)) {   // the input's amax slots, exact (amax_rows_kernel): the fp16 builds then take their tile scale from them
+            const int ns = (gin.nrows >> 7) + 2;
+            if (hipMalloc((void**)&XM, (size_t)ns * 4) != hipSuccess) { rc = fail(h, "hipMalloc failed"); break; }
+            hipMemsetAsync(XM, 0, (size_t)ns * 4, h->stream);
+            hipLaunchKernelGGL(amax_rows_kernel, dim3((gin.nrows + 127) / 128), dim3(256), 0, h->stream, (const float*)X, Cin, Cin, gin.nrows, XM);
+            e.xmax = XM; e.xmax_n = ns;
+        }
         if (transposed) {
             rc = launch_conv(h, L, X, Cin, Y, stride * Cout, gin, e);   // view rows = input frames
         } else if (stride == 2) {
@@ -2763,6 +2910,7 @@ int ev_op_conv1d(ev_handle* h, const float* d_x, const float* w, const float* bi
     } while (0);
     if (X) hipFree(X);
     if (Y) hipFree(Y);
+    if (XM) hipFree(XM);
     while (h->owned.size() > owned0) { hipFree(h->owned.back()); h->owned.pop_back(); }
     return rc;
 }

@@ -80,6 +80,14 @@ struct ConvParams {
     int kstack_mt, kstack_tap;              // stacked layers (a k-tap conv over a 1x1 conv along Cout): 32-channel tiles >= kstack_mt carry the
                                             // single tap kstack_tap, the tiles below it all ntaps (0 = not such a layer); conv_sk32_kernel only
     int sk_kb;                              // conv_gemm_sk_kernel: k-chunks per staging round
+    // Per-granule upper bounds of |tensor| ("amax slots": one word per 128 rows of a buffer's flattened padded axis, the fp32 bits of a bound on
+    // every value stored there since the slots were last zeroed; 0x7f800000 = a non-finite value was stored).  Producers leave them from their
+    // accumulators (ev_amax_emit), the fp16 builds take their tile scale from them instead of pre-scanning the X tile (conv_h16_kernel).
+    unsigned* ymax; int ymax_mul;           // producer: slots of Y (null: none); a row n of this launch covers rows n * ymax_mul .. of the slots' axis
+    const unsigned* rmax;                   // producer: slots of R (the residual's bound adds to the accumulators')
+    const unsigned* yold;                   // producer of a running sum (accum): the slots that hold the bound of what Y held BEFORE this launch (never ymax itself:
+                                            // a bound read from slots the same launch is updating would depend on timing — and the tile scales, hence the bits, with it)
+    const unsigned* xmax; int xmax_n;       // consumer: slots of X and their count (null: pre-scan)
     int stagger_slots;                      // workgroups co-resident per CU (0 = no start stagger), see conv_gemm_kernel
     unsigned long long* stamps;             // dbg bit 16: per-workgroup {start, first stage done, K loop done, end} s_memtime stamps
     int dbg;                                // ablation bits for tools/conv_bench.py: 1 skip X loads, 2 skip A loads, 4 skip epilogue
@@ -572,6 +580,98 @@ __device__ __forceinline__ void sk_arrive(const SkCtl& c, unsigned tag, int tid)
     }
 }
 
+__device__ __forceinline__ bool evh_is_finite(float m);
+// ---------------------------------------------------------------------------
+// Tile maxima from the producer.  The fp16 builds need max |x| over the rows a tile stages before they can split
+// them; conv_h16_kernel used to find it with a pre-scan — a second read of every X tile (198 GB of HBM traffic per config-2 step against
+// 156 GB before the fp16 builds, 5-10 % of a 3-tap layer's time).  Every producer on the vocoder's chain already holds the values in its
+// accumulators: it now leaves an UPPER BOUND of |y| per 128-row granule of its output (the maximum of |acc| over the wave tile's frames on
+// either side of the granule boundary it may straddle, plus the residual's and the running sum's own bounds — triangle inequality; leaky-relu,
+// masks and the / 3 of the resblock mean only shrink values), merged into the slot with an atomic maximum on the fp32 bits.  A bound, not the
+// maximum: the tile scale only needs max * scale < 65504, and the two-piece form keeps fp32-grade precision while the bound is within 2^17 of
+// the truth (error bound) — here it is within a small factor.  Slots are zeroed once per ev_hifigan call; a buffer rewritten
+// within the call keeps the larger of its generations' bounds.  An Inf in the accumulators marks the slot non-finite: the consumer then
+// repeats the search over the finite values of its tile (the pre-scan, kept as that slow path); NaNs never reach a maximum.
+// ---------------------------------------------------------------------------
+// The residual's and the running sum's bounds are requested at the START of the kernel (wave-uniform addresses: four loads whose latency
+// the K loop hides), the per-lane maxima are taken from the accumulators in front of the epilogue, and the wave's reduction + atomics
+// come AFTER the epilogue, where nothing waits for them.  (First version: loads, reduction and atomics together in front of the
+// epilogue — the narrow fused pairs, whose whole launch is a few microseconds per workgroup, ran 5-18 % slower: profiles/r04_amax_ab.txt.)
+struct EvAmax { float rlo, rhi, ylo, yhi, mlo, mhi; };
+__device__ __forceinline__ EvAmax ev_amax_begin(const ConvParams& p, int nw0, int nframes) {
+    EvAmax a = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!p.ymax || p.ymax_mul != 1) return a;
+    const int first = nw0 > 0 ? nw0 : 0;
+    if (first >= p.nrows || nw0 + nframes <= 0) return a;
+    const int g0 = first >> 7;
+    if (p.rmax) { a.rlo = __uint_as_float(p.rmax[g0]); a.rhi = __uint_as_float(p.rmax[g0 + 1]); }
+    if (p.yold) { a.ylo = __uint_as_float(p.yold[g0]); a.yhi = __uint_as_float(p.yold[g0 + 1]); }
+    return a;
+}
+__device__ __forceinline__ void ev_amax_emit(const ConvParams& p, const EvAmax& a, int nw0, int nframes, int lane) {
+    if (!p.ymax) return;
+    // a.mlo / a.mhi: this lane's maxima of |acc| over the wave tile's frames below / from the granule boundary bnd = ((max(nw0, 0) >> 7) + 1) << 7
+    float mlo = a.mlo, mhi = a.mhi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mlo = fmaxf(mlo, __shfl_xor(mlo, o, 64)); mhi = fmaxf(mhi, __shfl_xor(mhi, o, 64)); }
+    if (lane != 0) return;
+    const int first = nw0 > 0 ? nw0 : 0, last = nw0 + nframes - 1;
+    if (last < 0 || first >= p.nrows) return;
+    auto bits = [](float b) -> unsigned { return evh_is_finite(b) ? __float_as_uint(b * 1.000001f) : 0x7f800000u; };   // (rounded up: the sums below round to nearest)
+    if (p.ymax_mul == 1) {
+        const int g0 = first >> 7;
+        atomicMax(p.ymax + g0, bits(mlo + a.rlo + a.ylo));
+        if ((last >> 7) > g0) atomicMax(p.ymax + g0 + 1, bits(mhi + a.rhi + a.yhi));
+    } else {                                            // a polyphase transposed conv: row n holds ymax_mul output frames — one bound for all of them
+        const unsigned b = bits(fmaxf(mlo, mhi));
+        const int ga = (first * p.ymax_mul) >> 7, gb = ((last + 1) * p.ymax_mul - 1) >> 7;
+        for (int g = ga; g <= gb; ++g) atomicMax(p.ymax + g, b);
+    }
+}
+// this lane's share of the maxima for the two accumulator layouts (frames = columns of the C/D tiles)
+template <int TM, int TN>
+__device__ __forceinline__ void ev_amax_from_acc(const ConvParams& p, EvAmax& a, const f32x16 (&acc)[TM][TN], int nw0, int lane) {
+    if (!p.ymax) return;
+    const int bnd = (((nw0 > 0 ? nw0 : 0) >> 7) + 1) << 7;
+    float mlo = 0.f, mhi = 0.f;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) m = fmaxf(m, fmaxf(fabsf(acc[i][j][r]), fabsf(acc[i][j][r + 1])));
+        const bool lo = nw0 + j * 32 + (lane & 31) < bnd;
+        mlo = fmaxf(mlo, lo ? m : 0.f); mhi = fmaxf(mhi, lo ? 0.f : m);
+    }
+    a.mlo = mlo; a.mhi = mhi;
+}
+template <int QM, int QN>
+__device__ __forceinline__ void ev_amax_from_acc_q(const ConvParams& p, EvAmax& a, const f32x4 (&acc)[QM][QN], int nw0, int lane) {
+    if (!p.ymax) return;
+    const int bnd = (((nw0 > 0 ? nw0 : 0) >> 7) + 1) << 7;
+    float mlo = 0.f, mhi = 0.f;
+#pragma unroll
+    for (int b = 0; b < QN; ++b) {
+        float m = 0.f;
+#pragma unroll
+        for (int aa = 0; aa < QM; ++aa) m = fmaxf(m, fmaxf(fmaxf(fabsf(acc[aa][b][0]), fabsf(acc[aa][b][1])), fmaxf(fabsf(acc[aa][b][2]), fabsf(acc[aa][b][3]))));
+        const bool lo = nw0 + b * 16 + (lane & 15) < bnd;
+        mlo = fmaxf(mlo, lo ? m : 0.f); mhi = fmaxf(mhi, lo ? 0.f : m);
+    }
+    a.mlo = mlo; a.mhi = mhi;
+}
+// consumer: the bound of everything a tile stages (rows [row_lo, row_hi] of X), or a negative value when the slots cannot be used
+__device__ __forceinline__ float ev_amax_read(const ConvParams& p, int row_lo, int row_hi, int lane) {
+    int ga = (row_lo > 0 ? row_lo : 0) >> 7, gb = row_hi >> 7;
+    gb = gb < p.xmax_n - 1 ? gb : p.xmax_n - 1;
+    float m = 0.f;
+    for (int g = ga + (lane & 7); g <= gb; g += 8) m = fmaxf(m, __uint_as_float(p.xmax[g]));    // (at most three granules for a 128-row tile: one pass)
+#pragma unroll
+    for (int o = 4; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, m)));
+}
+
 // KB = 32-channel k-chunks staged per barrier pair (LDS row = 32*KB + 4 floats).  KB = 2 halves the number of
 // stage / barrier episodes — what the 1x1 and k=3 layers need (a 1x1 conv has only 4 k-groups = 32 MFMAs per wave
 // between two barrier pairs at KB = 1); wide-halo layers (k = 11, d = 5) already run 352 MFMAs per chunk and keep KB = 1
@@ -828,7 +928,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const ConvParams p) {
     __builtin_amdgcn_s_setprio(3);   // epilogue: see the note on memory phases above
     if ((p.dbg & 18) == 16 && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     if (p.dbg & 4) { if (acc[0][0][0] == 12345.678f) p.Y[0] = 1.f; return; }   // tools/conv_bench.py ablation: no epilogue
-    if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    if constexpr (LEAN == 1 || LEAN == 3) {                // (host: ymax only with these epilogues)
+        EvAmax am = ev_amax_begin(p, n0 + wn * (TN * 32), TN * 32);
+        ev_amax_from_acc<TM, TN>(p, am, acc, n0 + wn * (TN * 32), lane);
+        conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+        ev_amax_emit(p, am, n0 + wn * (TN * 32), TN * 32, lane);
+    } else if constexpr (LEAN != 0) conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     else conv_epilogue<TM, TN, FULL_ACT>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
     if ((p.dbg & 16) && threadIdx.x == 0) p.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 }
@@ -1394,6 +1499,7 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
         else dist = p.S - (n0 % p.S) + p.P;
         if (dist >= BN || n0 + dist >= p.nrows) return;
     }
+    EvAmax am = ev_amax_begin(p, n0 + wn * (TN * 32), TN * 32);   // (the residual's / running sum's bounds: requested now, used behind the epilogue)
     const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
     const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
 
@@ -1483,9 +1589,12 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
             mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
             return mx;
         };
-        float mx = scan(std::false_type{});
+        // the producer's bound for the granules this tile stages (ev_amax_emit), when the input has one: no pre-scan.  A non-finite mark
+        // sends the tile to the finite-only search — the pre-scan, kept as that slow path and for inputs without slots.
+        float mx = p.xmax ? ev_amax_read(p, n0 - p.halo_lo, n0 + BN + p.halo_hi - 1, lane) : -1.f;
+        if (mx < 0.f) mx = scan(std::false_type{});
         if (!evh_is_finite(mx)) {                           // an Inf in the tile (workgroup-uniform): the finite maximum sets the scale
-            ev_lds_barrier();                               // (every wave has read red[])
+            if (!p.xmax) ev_lds_barrier();                  // (every wave has read red[])
             mx = scan(std::true_type{});
         }
         xs = (p.dbg & 2048) ? 1024.f : evh_scale_for(mx);
@@ -1582,7 +1691,9 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] *= acc_out;
     __builtin_amdgcn_s_setprio(3);
+    ev_amax_from_acc<TM, TN>(p, am, acc, n0 + wn * (TN * 32), lane);
     conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+    ev_amax_emit(p, am, n0 + wn * (TN * 32), TN * 32, lane);
     } else {
         // ---------------- the 16 x 16 x 32 form ----------------
         f32x4 acc[QM][QN];
@@ -1644,7 +1755,9 @@ __global__ __launch_bounds__(256, 2) void conv_h16_kernel(const ConvParams p) {
 #pragma unroll
             for (int b = 0; b < QN; ++b) acc[a][b] *= acc_out;
         __builtin_amdgcn_s_setprio(3);
+        ev_amax_from_acc_q<QM, QN>(p, am, acc, n0 + wn * (TN * 32), lane);
         conv_epilogue_lean_q<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane);
+        ev_amax_emit(p, am, n0 + wn * (TN * 32), TN * 32, lane);
     }
 }
 
@@ -1913,6 +2026,12 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
     int nst = 0;                                       // diagnostic (EV_BAL_STAMPS): up to 16 s_memrealtime stamps per workgroup
     auto stamp = [&]() { if (p.stamps && tid == 0 && nst < 16) p.stamps[16 * g + nst] = __builtin_amdgcn_s_memrealtime(); ++nst; };
     stamp();
+    // Start stagger (EV_BAL_STAGGER=<us>, A/B): the two workgroups of a CU run the same program on the same amount of work, so they stage (HBM-bound,
+    // all workgroups of the launch at once) and issue MFMAs (both on the same SIMDs) IN PHASE — per-workgroup stamps: 3.5 us staged + 4 us
+    // MFMAs per chunk where one workgroup alone on the matrix pipes needs 2.2.  The second half of the grid (the workgroups that share a CU
+    // with the first half under the dispatcher's round-robin; a placement assumption for speed only) starts late by about half a chunk period.
+    if (p.stagger_slots > 0 && g >= (int)(gridDim.x >> 1))
+        for (int i_ = 0; i_ < p.stagger_slots; ++i_) __builtin_amdgcn_s_sleep(32);      // 32 x 64 cycles ~ 1 us per step
 
     while (u < ue) {
         const int t = u / nchunks, c0 = u - t * nchunks;
@@ -3014,6 +3133,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16_kernel(const PairPar
     }
     const int KG16 = p.Kpad >> 4;
     const unsigned wlane = (unsigned)lane * 16u;
+    EvAmax am = ev_amax_begin(p, g0 + wn * (TN * 32), TN * 32);   // (the residual's / running sum's bounds: requested now, used behind the epilogue)
     const unsigned wbase = (unsigned)(wm * KG16) * 2048u;
     const __amdgpu_buffer_rsrc_t rX = ev_rsrc(p.X);
     f32x16 acc[TM][TN];
@@ -3109,6 +3229,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16_kernel(const PairPar
             tmx = wg_max(mx, 8);
         }
         sx = evh_scale_for(tmx);
+        am.rlo = am.rhi = tmx;                          // the residual IS this tile's input: its bound for the amax slots is the tile maximum just found (no slots of X needed)
 #pragma unroll
         for (int q = 0; q < XPASS; ++q) {
             const int r = q * RPS + srow;
@@ -3190,7 +3311,9 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16_kernel(const PairPar
 #pragma unroll
             for (int r16 = 0; r16 < 16; ++r16) acc[0][j][r16] *= inv2;
     }
+    ev_amax_from_acc<TM, TN>(p, am, acc, g0 + wn * (TN * 32), lane);
     conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
+    ev_amax_emit(p, am, g0 + wn * (TN * 32), TN * 32, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -3231,6 +3354,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16q_kernel(const PairPa
         if (dist >= pp.out_rows || n0 + dist >= p.nrows) return;
     }
     const unsigned wlane = (unsigned)lane * 16u;
+    EvAmax am = ev_amax_begin(p, g0 + wn * (TN * 32), TN * 32);   // (the residual's / running sum's bounds: requested now, used behind the epilogue)
     const unsigned wbase = (unsigned)(wm * 2 * H) * 2048u;   // this wave's two 16-channel row tiles: m16 = 2 wm + a, H steps of 2 KiB each
     const __amdgpu_buffer_rsrc_t rX = ev_rsrc(p.X);
     f32x4 acc[QM][QN];
@@ -3327,6 +3451,7 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16q_kernel(const PairPa
             tmx = wg_max(mx, 8);
         }
         sx = evh_scale_for(tmx);
+        am.rlo = am.rhi = tmx;                          // the residual IS this tile's input: its bound for the amax slots is the tile maximum just found (no slots of X needed)
 #pragma unroll
         for (int q = 0; q < XPASS; ++q) {
             const int r = q * RPS + srow;
@@ -3409,7 +3534,9 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16q_kernel(const PairPa
 #pragma unroll
             for (int b = 0; b < QN; ++b) acc[a][b] *= inv2;
     }
+    ev_amax_from_acc_q<QM, QN>(p, am, acc, g0 + wn * (TN * 32), lane);
     conv_epilogue_lean_q<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + pp.out_rows);
+    ev_amax_emit(p, am, g0 + wn * (TN * 32), TN * 32, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -5845,6 +5972,36 @@ __global__ __launch_bounds__(256) void zero_pads_kernel(const ZeroPadParams zp) 
         const int row = pr < P ? pr : pr + T;
         base[((long)b * S + row) * C4 + c] = z;
     }
+}
+
+// zero fill as a KERNEL (a captured ev_cfm_decode re-zeroes its plan with this instead of a memset node: a captured call then consists of kernel
+// nodes only)
+__global__ __launch_bounds__(256) void zero_fill_kernel(f32x4* __restrict__ p, size_t n16) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
+}
+
+// amax slots of a tensor that no producer bounded (operator-level tests, ev_op_conv1d): one workgroup per 128-row granule, the exact
+// maximum of |x| over its rows (non-finite values mark the slot as the producers do)
+__global__ __launch_bounds__(256) void amax_rows_kernel(const float* __restrict__ X, int ld, int C, int nrows, unsigned* slots) {
+    __shared__ float red[4];
+    const int g = blockIdx.x, r0 = g * 128;
+    float m = 0.f;
+    bool bad = false;
+    const int c4n = C / 4;
+    for (int i = threadIdx.x; i < 128 * c4n; i += 256) {
+        const int r = r0 + i / c4n, c = (i % c4n) * 4;
+        if (r >= nrows) break;
+        const f32x4 v = *(const f32x4*)(X + (size_t)r * ld + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float a = fabsf(v[e]); if ((__float_as_uint(a) & 0x7f800000u) == 0x7f800000u) bad = bad || (a == a); else m = fmaxf(m, a); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const bool anybad = __syncthreads_or(bad);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) slots[g] = anybad ? 0x7f800000u : __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
 // ---------------------------------------------------------------------------

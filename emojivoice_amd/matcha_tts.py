@@ -75,6 +75,7 @@ class MatchaTTS:
         self._enc_cfg = (n_heads_encoder, n_layers_encoder)
         self.encoder_stage = "device"   # "device": ev_text_encoder (HIP, through the C ABI); "host": the plain-torch TextEncoder
         self.rng = "cpu"   # "cpu": z drawn exactly as the reference CPU run draws it (seed parity); "device": torch.cuda RNG
+        self.decode_graphs = None   # enable_decode_graphs(): the CFM decode replayed from HIP graphs (one per shape)
         self.engine: Optional[Engine] = None
         self.device = torch.device("cpu")
         self.to(device)
@@ -208,7 +209,74 @@ class MatchaTTS:
             z = self.draw_noise(B, Tp)
         x0 = (z.to(self.device) * temperature).contiguous()
         mu_c = mu_y.contiguous()
+        if self.decode_graphs is not None and spk is not None:
+            return self.decode_graphs.run(mu_c, y_lengths, spk, x0, n_timesteps)
         return self.engine.cfm_decode2(mu_c, y_lengths, spk, x0, n_timesteps, self.mel_std, self.mel_mean)
+
+    def enable_decode_graphs(self, max_graphs: int = 256) -> "DecodeGraphs":
+        """Replay the CFM decode from HIP graphs, one per (batch, padded length, step count) — the streaming loop's ~700 launches per
+        utterance (feel_me.py:189-203) become one ``hipGraphLaunch``.  Call after ``warmup(max_frames=...)``: a captured decode needs
+        the workspace to be there already.  Results are those of the eager call, bit for bit (``tests/test_gpu_configs.py``)."""
+        self.decode_graphs = DecodeGraphs(self, max_graphs)
+        return self.decode_graphs
+
+
+class DecodeGraphs:
+    """LRU cache of captured ``ev_cfm_decode2`` calls of one ``MatchaTTS``.  A graph owns static input / output tensors (inputs are
+    copied in, outputs cloned out: ~0.4 MB per utterance); the engine keeps the graphs of different shapes valid beside each other
+    and beside eager calls (include/emojivoice.h, "Graph capture").  A length that cannot be captured (workspace too small for it:
+    not reserved) falls back to the eager call — and says so once."""
+
+    def __init__(self, model: MatchaTTS, max_graphs: int = 256):
+        self.model, self.max_graphs = model, int(max_graphs)
+        self.stream = torch.cuda.Stream(device=model.device)
+        self._cache: "Dict[tuple, dict]" = {}
+        self._order: list = []
+        self.hits = self.captures = self.fallbacks = 0
+        self._warned = False
+
+    def _capture(self, key, mu, lengths, spk, x0, n_timesteps):
+        m = self.model
+        ent = {"mu": mu.clone(), "len": lengths.to(m.device, torch.int32).clone(), "spk": spk.to(torch.float32).contiguous().clone(), "x0": x0.clone()}
+        # one eager call first: it leaves the time-MLP output for this step count on the device (a captured call must find it there,
+        # include/emojivoice.h "Graph capture") and is the plain-library error path for anything the shape cannot do
+        m.engine.cfm_decode2(ent["mu"], ent["len"], ent["spk"], ent["x0"], n_timesteps, m.mel_std, m.mel_mean)
+        cur = torch.cuda.current_stream(m.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                ent["dec"], ent["mel"] = m.engine.cfm_decode2(ent["mu"], ent["len"], ent["spk"], ent["x0"], n_timesteps, m.mel_std, m.mel_mean)
+        cur.wait_stream(self.stream)
+        ent["graph"] = g
+        self.captures += 1
+        return ent
+
+    def run(self, mu, lengths, spk, x0, n_timesteps):
+        key = (tuple(mu.shape), int(n_timesteps))
+        ent = self._cache.get(key)
+        if ent is None:
+            try:
+                ent = self._capture(key, mu, lengths, spk, x0, n_timesteps)
+            except Exception as e:  # noqa: BLE001 - the eager call is always available
+                self.fallbacks += 1
+                if not self._warned:
+                    self._warned = True
+                    print(f"[emojivoice_amd] decode graph for shape {key} not captured ({type(e).__name__}: {e}); running eagerly")
+                m = self.model
+                return m.engine.cfm_decode2(mu, lengths, spk, x0, n_timesteps, m.mel_std, m.mel_mean)
+            self._cache[key] = ent
+            self._order.append(key)
+            if len(self._order) > self.max_graphs:
+                old = self._order.pop(0)
+                self._cache.pop(old, None)
+        else:
+            self.hits += 1
+            self._order.remove(key)
+            self._order.append(key)
+        ent["mu"].copy_(mu); ent["len"].copy_(lengths); ent["spk"].copy_(spk); ent["x0"].copy_(x0)
+        ent["graph"].replay()
+        return ent["dec"].clone(), ent["mel"].clone()
 
 
 # ---------------------------------------------------------------------------

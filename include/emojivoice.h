@@ -26,12 +26,17 @@
  *   - The handle owns the re-laid-out weights and a workspace that grows on demand, geometrically (growth = a wait for the
  *     handle's streams + hipFree + hipMalloc).  ev_reserve sizes everything once, up front, so that no later call at or below
  *     the reserved shape allocates or waits (a streaming server reserves its longest utterance: ev_alloc_count stays put).
- *   - Graph capture: the first call at a new (B, Tp) plans and zeroes the workspace and is not capturable; later ev_cfm_decode
- *     calls at that shape are (they enqueue kernels and one pinned-memory copy and never wait on the host).  A captured call
- *     stages its per-step time embeddings in pinned memory that the handle never reuses, and BINDS the handle to its (B, Tp):
- *     afterwards ev_cfm_decode at another shape, a growth of the workspace, or more Euler steps than the workspace is planned for
- *     (64, or the largest n_steps of an earlier call) return an error instead of pulling memory from under the graph; eager calls
- *     at the captured shape with any admissible n_steps are fine.  At most 8 captured calls per handle.
+ *   - Graph capture: ev_cfm_decode is capturable at any (B, Tp) the workspace already holds (ev_reserve, or an earlier eager call at the
+ *     largest shape: planning must not allocate under capture): it enqueues kernels, one memset and one pinned-memory copy and never
+ *     waits on the host.  A handle may hold captured calls of MANY shapes (ABI 4; a serving loop keeps one graph per utterance length)
+ *     and serve eager calls of any shape in between: once a call has been captured, every call on the handle — captured or eager —
+ *     begins by re-zeroing the estimator's part of the workspace for its own plan, so none depends on what another left there.  A
+ *     captured call contains kernels and one memset only: the time-MLP output for its step count must already be on the device, i.e.
+ *     one EAGER ev_cfm_decode with the same n_steps must have run on the handle before (the handle keeps that output per step count;
+ *     a host-to-device copy captured from pinned memory is not safe to replay on this runtime: later eager copies recycle its staging).
+ *     What returns an error instead of pulling memory from under the graphs: a growth of the workspace beyond what is reserved, more
+ *     Euler steps than the workspace is planned for (64, or the largest n_steps of an earlier call), a captured call with a step
+ *     count no eager call has used.
  *   - Layout at the boundary is the reference's: mel-like tensors are (B, 80, T)
  *     channel-major contiguous; waveforms are (B, 256*T) contiguous.
  *   - Every function returns 0 on success, non-zero on failure; the message is
@@ -49,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 3   /* 3: ev_set_arithmetic / ev_get_arithmetic, ev_profile_read_split, test hooks; everything of version 2 unchanged */
+#define EV_ABI_VERSION 4   /* 4: ev_dbg_set_amax; 3: ev_set_arithmetic / ev_get_arithmetic, ev_profile_read_split, test hooks; everything of earlier versions unchanged */
 
 typedef struct ev_handle ev_handle;
 
@@ -192,6 +197,12 @@ int ev_dbg_last_cfg(ev_handle *h);
  * resblock-style conv (prologue leaky-relu, bias, residual) at a given geometry with HIP events on the default stream;
  * dbg = ablation bits, cfg = forced tile configuration (< 0: the engine's own choice). */
 int ev_dbg_conv_bench(ev_handle *h, int Cin, int Cout, int K, int dil, int B, int T, int P, int iters, int dbg, int cfg, float *ms_out);
+
+/* Diagnostic / A-B switch: the fp16 builds need max |x| over the rows a tile stages.  on = 1 (default): they take it from the bounds their
+ * producers left per 128-row granule (every launch of ev_hifigan's chain leaves an upper bound of |y| from its accumulators — no second read
+ * of the input); on = 0: every tile pre-scans its input (the behaviour before ABI 4; also what inputs without bounds get).  The environment
+ * variable EV_NO_AMAX=1 presets 0 for handles created afterwards.  Results differ only through the choice of the power-of-two block scale. */
+int ev_dbg_set_amax(ev_handle *h, int on);
 
 /* Diagnostic: the control words of the balanced ("stream-K") launches (ev_kernels.h, SkCtl) after a device synchronisation:
  * out3 = {launches so far (epoch), arrivals of an unfinished launch (0), hand-off waits that ran out and were recomputed}. */

@@ -30,7 +30,7 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), f"{n} declared in include/emojivoice.h but not exported"
     assert set(names) == set(_lib.EXPORTS)
     lib.ev_abi_version.restype = ctypes.c_int
-    assert lib.ev_abi_version() == 3
+    assert lib.ev_abi_version() == 4
 
 
 def test_driver_build_hook_accepts_the_library():
@@ -39,7 +39,7 @@ def test_driver_build_hook_accepts_the_library():
 
     if not os.path.exists(_lib.LIB_PATH):
         _lib.build_library()
-    assert entry._check_abi(_lib.load_library()) == 3
+    assert entry._check_abi(_lib.load_library()) == 4
 
 
 def test_no_cpu_fallback():

@@ -43,7 +43,7 @@ def test_native_library_is_loaded():
     from emojivoice_amd import _lib
 
     lib = _lib.load_library()
-    assert lib.ev_abi_version() == 3
+    assert lib.ev_abi_version() == 4
     with open("/proc/self/maps") as f:
         assert "libemojivoice_hip.so" in f.read()
 

@@ -123,3 +123,62 @@ def test_checkpoint_with_tiny_weights_loads_and_runs_on_the_fp32_build():
     ref = O.hifigan_forward(sd, mel, W.HIFIGAN_V1)
     assert float((wav - ref).pow(2).mean().sqrt()) <= 1e-4
     voc.engine.close()
+
+
+def test_tile_maximum_in_a_neighbour_tiles_halo(eng):
+    """The fp16 builds take a tile's scale from the producers' per-granule bounds (amax slots) of EVERY granule the tile stages, halo rows
+    included.  Here the largest value by far sits in the LAST row of one 128-row granule, i.e. in the halo of the
+    next tile only: a scale taken from that tile's own granule would be 2^24 too large and the halo row would overflow in fp16."""
+    g = torch.Generator().manual_seed(14)
+    B, C, T, K, d = 1, 128, 140000, 7, 3                    # halo 9 on either side; op geometry pads every utterance with 32 rows
+    w = torch.randn(C, C, K, generator=g) / (C * K) ** 0.5
+    b = torch.zeros(C)
+    x = torch.randn(B, C, T, generator=g) * 1e-3
+    t_spike = 127 - 32 + 128 * 40                           # flattened row 128 * 40 + 127: last row of granule 40
+    x[0, :, t_spike] = 3e4
+    ref = F.conv1d(x.double(), w.double(), b.double(), padding=d * (K - 1) // 2, dilation=d)[0]
+    near = torch.zeros(T, dtype=torch.bool)
+    near[t_spike - 9: t_spike + 10] = True
+    orig = eng.arithmetic()
+    try:
+        eng.set_arithmetic(16)
+        for amax in (True, False):
+            eng.set_amax(amax)
+            y = eng.op_conv1d(x.cuda(), w, b, dilation=d, padding=d * (K - 1) // 2).cpu().double()[0]
+            assert eng.last_cfg() == 46
+            assert bool(torch.isfinite(y).all()), f"amax={amax}: overflow"
+            e = (y - ref).abs()
+            assert float(e[:, near].max() / ref[:, near].abs().max()) <= 1e-5, (amax, float(e[:, near].max()))
+            far = ~near
+            far[128 * 39 - 32: 128 * 42] = False            # the three tiles whose scale the spike sets (their quiet rows: see the dynamic-range test)
+            assert float(e[:, far].max() / ref[:, far].pow(2).mean().sqrt()) <= 2e-5, (amax, float(e[:, far].max()))
+    finally:
+        eng.set_amax(True)
+        eng.set_arithmetic(orig)
+
+
+def test_vocoder_with_and_without_amax_slots_agree():
+    """ev_hifigan end to end, 16 x 516 frames (deep grids: conv_h16_kernel on every level-1 / level-2 layer): the chain whose tile scales
+    come from the producers' bounds against the same chain with every tile pre-scanning its input, and both against the oracle.  The
+    first half of every other utterance is near-silent (mel at -11.5): tiles straddle silence and speech."""
+    from emojivoice_amd import weights as W
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+    from oracle import matcha_oracle as O
+
+    voc_sd = W.synthetic_hifigan_state()
+    voc = Generator(AttrDict(v1)).to("cuda:0")
+    voc.load_state_dict(voc_sd)
+    g = torch.Generator().manual_seed(15)
+    mel = torch.randn(16, 80, 516, generator=g) * 2.0 - 5.0
+    mel[::2, :, :258] = -11.5
+    voc._sync_engine()
+    voc.engine.set_amax(True)
+    y_on = voc(mel.cuda()).cpu()
+    voc.engine.set_amax(False)
+    y_off = voc(mel.cuda()).cpu()
+    voc.engine.set_amax(True)
+    ref = O.hifigan_forward(voc_sd, mel[:3], W.HIFIGAN_V1)
+    assert float((y_on - y_off).pow(2).mean().sqrt()) <= 1e-5
+    for y in (y_on, y_off):
+        assert float((y[:3] - ref).pow(2).mean().sqrt()) <= 1e-4
+    voc.engine.close()

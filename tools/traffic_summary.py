@@ -19,4 +19,11 @@ res = {"conv_launches": nf["conv"], "fetch_GB_raw": f["conv"] * 1024 / 1e9, "fet
 res["hbm_GB_per_step"] = (res["fetch_GB_corrected"] + res["write_GB"]) / steps
 res["hbm_MB_per_launch"] = 1e3 * (res["fetch_GB_corrected"] + res["write_GB"]) / max(nf["conv"], 1)
 res["other_kernels_GB"] = (2 * f["other"] + w["other"]) * 1024 / 1e9
+# which library the passes ran on: sha256 of the three sources the library is built from (bench.py compares it with the running library's)
+import hashlib, os
+here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+hsh = hashlib.sha256()
+for rel in ("emojivoice_amd/csrc/ev_kernels.h", "emojivoice_amd/csrc/ev_engine.hip", "include/emojivoice.h"):
+    hsh.update(open(os.path.join(here, rel), "rb").read())
+res["library_source_sha16"] = hsh.hexdigest()[:16]
 print(json.dumps(res))
