@@ -527,6 +527,7 @@ def main():
     torch.cuda.synchronize()
     sk_engines = [model.engine] + [m.engine for m in extra_models[0::2]]   # the decoders' handles: their balanced launches hand partial tiles over
     sk0 = [e.sk_stats() for e in sk_engines]
+    tk0 = [e.sk_taken() for e in sk_engines]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         full, wav, mel = step()
@@ -534,8 +535,11 @@ def main():
     D.barrier()
     dt = time.perf_counter() - t0
     sk1 = [e.sk_stats() for e in sk_engines]
+    tk1 = [e.sk_taken() for e in sk_engines]
     handoffs = {"balanced_launches": int(sum(b[0] - a[0] for a, b in zip(sk0, sk1))), "waits_ran_out": int(sum(b[2] - a[2] for a, b in zip(sk0, sk1))),
-                "note": "over the timed steps, all pipelines: launches of the balanced persistent builds and hand-off waits that ran out (the owner then recomputed the share itself)"}
+                "shares_taken_over": int(sum(b - a for a, b in zip(tk0, tk1))),
+                "note": "over the timed steps, all pipelines: launches of the balanced persistent builds; hand-off waits that ran out (a contributor that had started did not "
+                        "deliver within the spin limit: the owner recomputed its share); shares an owner took over at once because the contributor had not started (not resident)"}
     dt_rank = dt
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     per_rank_ms = [round(dt / args.steps * 1e3, 2)]

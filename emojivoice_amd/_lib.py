@@ -23,7 +23,7 @@ EXPORTS = [
     "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read", "ev_profile_read_split", "ev_dbg_last_cfg", "ev_set_arithmetic", "ev_get_arithmetic",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_split_pieces", "ev_op_attention", "ev_op_ln_mlp", "ev_set_mrf_streams_max",
-    "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out", "ev_dbg_set_amax",
+    "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out", "ev_dbg_set_amax", "ev_dbg_sk_taken",
 ]
 
 
@@ -102,6 +102,8 @@ def load_library() -> C.CDLL:
     lib.ev_set_arithmetic.argtypes = [vp, i32]
     lib.ev_get_arithmetic.argtypes = [vp]
     lib.ev_dbg_set_amax.argtypes = [vp, i32]
+    lib.ev_dbg_sk_taken.argtypes = [vp]
+    lib.ev_dbg_sk_taken.restype = C.c_int64
     lib.ev_op_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
     lib.ev_op_groupnorm_mish.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.ev_op_layernorm.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
@@ -290,6 +292,10 @@ class Engine:
 
     def alloc_count(self) -> int:
         return int(self.lib.ev_alloc_count(self.h))
+
+    def sk_taken(self) -> int:
+        """Contributor shares taken over by their owners (work stealing of the balanced launches) since the handle was created."""
+        return int(self.lib.ev_dbg_sk_taken(self.h))
 
     def sk_stats(self):
         """(balanced launches so far, arrivals of an unfinished one, hand-off waits that ran out) — diagnostic."""

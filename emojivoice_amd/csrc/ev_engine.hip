@@ -160,7 +160,8 @@ struct ev_handle {
     hipEvent_t mrf_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // balanced ("stream-K") launches, see SkCtl in ev_kernels.h: control words + flags (zeroed once) and the partial-tile slots
     int ncu = 0;                    // compute units of the device
-    unsigned* sk_ctrl = nullptr;    // [0] epoch [1] arrivals [2] timed-out waits | flags from word 16 on
+    unsigned* sk_ctrl = nullptr;    // [0] epoch [1] arrivals [2] timed-out waits [3] shares taken over | flags from word 16 on | claims from word 16 + EV_SK_MAXWG on
+    unsigned sk_seq = 0;            // sequence number of the balanced launches that use claims (conv_h16_bal_kernel, ln_mlp_h16_kernel)
     float* sk_part = nullptr;
     int split_terms = 16;           // arithmetic of the deep layers' products (ev_set_arithmetic; EV_SPLIT presets it): 16 = shipped: two block-scaled
                                     // fp16 pieces per operand, three products (fp32-grade); 6 = three bf16 pieces, six products (fp32-grade, no
@@ -169,6 +170,7 @@ struct ev_handle {
     bool amax_emitted = false;      // set by every launch_conv / launch_pair: the launch left per-granule bounds of its output in Epi::ymax
     int n_fp32_only_layers = 0;     // layers whose weights are not the exact sum of three bf16 pieces (tiny or non-finite): they keep the fp32 MFMA build
     int last_cfg = -1;              // build the last launch_conv / launch_pair took (ev_dbg_last_cfg: tests assert that a shape ran on the build they mean)
+    bool sk_steal = true;           // EV_NO_SK_STEAL=1: owners wait for absent contributors (up to the spin limit) instead of taking their shares over (A/B)
     bool sk_balance = true;         // EV_NO_SK_BALANCE=1: every launch one tile per workgroup (A/B runs)
     bool sk_spread = false;         // EV_SK_SPREAD=1: launches of fewer row tiles than CUs (small batches) spread their units over up to 2 x CUs workgroups
     int sk_wgs = 2;                 // EV_SK_WGS=<1..3>: persistent workgroups per CU of a balanced ln_mlp launch (A/B runs)
@@ -607,7 +609,7 @@ constexpr int EV_SK_PART_FLOATS = 16384;   // largest partial accumulator tile h
 int ensure_sk(ev_handle* h, bool hot_path = true) {
     if (h->sk_ctrl) return 0;
     if (hot_path) ++h->n_allocs;   // (every loader and ev_reserve call this first, so a hot call never gets here; if one ever does, ev_alloc_count shows it)
-    const size_t words = 16 + EV_SK_MAXWG;
+    const size_t words = 16 + 2 * EV_SK_MAXWG;         // control words | one flag per workgroup | one claim word per workgroup (work stealing)
     HIPCHK(h, hipMalloc((void**)&h->sk_ctrl, words * sizeof(unsigned)));
     HIPCHK(h, hipMemset(h->sk_ctrl, 0, words * sizeof(unsigned)));
     HIPCHK(h, hipMalloc((void**)&h->sk_part, (size_t)EV_SK_MAXWG * 2 * EV_SK_PART_FLOATS * sizeof(float)));   // (freed by ev_destroy)
@@ -666,6 +668,7 @@ int launch_h16_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
     const int G = wpc * h->ncu;
     p.sk.ctrl = h->sk_ctrl; p.sk.flags = h->sk_ctrl + 16; p.sk.part = h->sk_part; p.sk.part_floats = EV_SK_PART_FLOATS;
     p.sk.q = (int)(U / G); p.sk.r = (int)(U % G); p.sk.spin_limit = h->sk_spin;
+    if (h->sk_steal) { p.sk.claims = h->sk_ctrl + 16 + EV_SK_MAXWG; p.sk.seq = ++h->sk_seq; }
     const size_t xs = (size_t)(BN + ((lo.halo + 7) & ~7)) * EVH_RSB;
     constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4) * sizeof(float);
     size_t smem = xs > es ? xs : es;
@@ -1180,6 +1183,7 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
             mp.W1h = L1.Wh; mp.W2h = L2->Wh; mp.w1_scale = L1.wh_scale; mp.w2_scale = L2->wh_scale;
             mp.sk.q = (int)(U / grid); mp.sk.r = (int)(U % grid); mp.sk.spin_limit = h->sk_spin;
             mp.sk.ctrl = h->sk_ctrl; mp.sk.flags = h->sk_ctrl + 16; mp.sk.part = h->sk_part; mp.sk.part_floats = EV_SK_PART_FLOATS;
+            if (h16 && h->sk_steal) { mp.sk.claims = h->sk_ctrl + 16 + EV_SK_MAXWG; mp.sk.seq = ++h->sk_seq; }
             if (L1.Mpad > 1024) return fail(h, "launch_mlp: hidden width %d > 1024 (LDS table of the SnakeBeta vectors)", L1.Mpad);
             const size_t smem = h16 ? (size_t)64 * (4 * 256 + 16) + (size_t)64 * (4 * 128 + 16) + 16 + (size_t)2 * L1.Mpad * sizeof(float) + 64
                                     : (size_t)64 * (6 * 256 + 16) + (size_t)64 * (6 * 128 + 16) + 16 + (size_t)2 * L1.Mpad * sizeof(float);
@@ -1999,6 +2003,7 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     { const char* sp = getenv("EV_SPLIT"); if (sp && *sp) { const int t = atoi(sp); h->split_terms = (t == 0 || t == 3 || t == 6 || t == 9 || t == 16) ? t : 16; } }
     { const char* fp = getenv("EV_NO_SK_BALANCE"); if (fp && *fp && *fp != '0') h->sk_balance = false; }
     { const char* fp = getenv("EV_SK_SPIN"); if (fp && *fp) h->sk_spin = atoi(fp); }
+    if (getenv("EV_NO_SK_STEAL")) h->sk_steal = false;
     { const char* fp = getenv("EV_SK_WGS"); if (fp && *fp) h->sk_wgs = std::min(3, std::max(1, atoi(fp))); }
     { const char* fp = getenv("EV_SK_SPREAD"); if (fp && *fp) h->sk_spread = *fp != '0'; }
     if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) h->ncu = 0;
@@ -2496,6 +2501,16 @@ int ev_dbg_sk_stats(ev_handle* h, uint32_t* out3) {
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out3, h->sk_ctrl, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return 0;
+}
+
+// Diagnostic (ABI 4): contributor shares that owners of the balanced launches took over because the contributor had not started (work
+// stealing, ev_kernels.h sk_wait_many), since the handle was created; -1 on error.  Synchronises the device.
+int64_t ev_dbg_sk_taken(ev_handle* h) {
+    if (!h) return -1;
+    if (!h->sk_ctrl) return 0;
+    uint32_t v = 0;
+    if (hipSetDevice(h->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess || hipMemcpy(&v, h->sk_ctrl + 3, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (int64_t)v;
 }
 
 int ev_estimator(ev_handle* h, const float* d_x, const float* d_mu, const int32_t* d_lengths, const float* d_spk, float t,

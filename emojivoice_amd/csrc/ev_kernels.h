@@ -41,6 +41,8 @@ struct SkCtl {
     int part_floats;
     int q, r;            // units per workgroup: start(x) = x * q + min(x, r)
     int spin_limit;      // polls before an owner gives up waiting
+    unsigned* claims;    // one word per workgroup (null: no stealing): 2 seq = "started its share of this launch", 2 seq + 1 = "its owner has taken the share over"
+    unsigned seq;        // launch sequence number of the handle (host-side counter: monotonic, so the words never need a reset)
     int lds_word;        // conv_gemm_bal_kernel: byte offset of the sk_wait word in dynamic LDS
     // conv_gemm_bal_kernel, layers whose M tiles differ in cost (a 3-tap conv stacked over a 1x1 conv: half of the M tiles carry one
     // tap): the workgroups share WEIGHTED positions — a unit of M tile mt weighs wtab[mt] (its taps, 4 bits each, up to 16 M tiles) —
@@ -545,23 +547,60 @@ __device__ __forceinline__ bool sk_wait(const SkCtl& c, int gi, unsigned tag, in
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (the word may be rewritten by the next wait)
     return ok;
 }
+// Work stealing (round 4).  An owner used to wait — up to the spin limit, ~4.5 ms — for a contributor that was not even RESIDENT yet: with two
+// pipelines in flight the vocoder's workgroups hold CU slots and about one balanced launch in ten had such a wait run out (then the owner
+// recomputed the share: duplicated work after a long stall).  Now every workgroup announces itself (`sk_claim_start`: one atomic maximum of
+// 2 seq at kernel start) and an owner that finds a contributor's word below 2 seq takes the share over at once (compare-and-swap to 2 seq + 1)
+// and computes it itself, as a separate partial sum — the bits the contributor would have delivered; the contributor, when it finally starts,
+// sees 2 seq + 1 and skips that share.  Every race resolves to either "wait for a contributor that has started" or "compute it here": never a
+// different result, never a hang.  (A replayed hipGraph repeats seq: stale marks then only cost efficiency — both sides still agree.)
+__device__ __forceinline__ unsigned sk_claim_start(const SkCtl& c, int g, int tid) {    // -> previous value of the word (lane 0 of wave 0 only)
+    unsigned prev = 0;
+    if (c.claims && tid == 0) prev = __hip_atomic_fetch_max((ev_gu32*)(c.claims + g), 2u * c.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return prev;
+}
+// contributor side: has this workgroup's first share (the part of a tile that belongs to another owner) been taken over?  All threads call.
+__device__ __forceinline__ bool sk_claim_taken(const SkCtl& c, unsigned prev, int tid, int* word) {
+    if (!c.claims) return false;
+    if (tid == 0) *word = (prev == 2u * c.seq + 1u) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const bool taken = __builtin_amdgcn_readfirstlane(*word) != 0;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (the word may be rewritten by a later wait)
+    return taken;
+}
 // The same for the n (<= 64) consecutive workgroups gi .. gi + n - 1: lane k of wave 0 polls flag gi + k, so the flags are read in parallel
-// and ONE acquire covers them all.  Returns how many LEADING flags were up when the polling ended (n, or fewer after the spin limit).
+// and ONE acquire covers them all.  Returns how many LEADING flags were up when the polling ended (n; fewer when the first missing contributor
+// has been taken over — no wait — or after the spin limit).
 __device__ __forceinline__ int sk_wait_many(const SkCtl& c, int gi, int n, unsigned tag, int tid, int* word) {
     if (tid < 64) {                                    // wave 0 (a whole wave: scalar branch)
-        unsigned long long up = 0;
+        unsigned long long up = 0, taken = 0;
         const unsigned long long want = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        if (c.claims) {                                // which contributors have not started: take their shares over
+            bool mine = false;
+            if (tid < n) {
+                ev_gu32* w = (ev_gu32*)(c.claims + gi + tid);
+                const unsigned started = 2u * c.seq, stolen = started + 1u;
+                unsigned v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v == stolen) mine = true;          // (taken over by an earlier call of this owner)
+                else if (v != started) {
+                    unsigned expect = v;
+                    mine = __hip_atomic_compare_exchange_strong(w, &expect, stolen, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) || expect == stolen;
+                }
+            }
+            taken = __ballot(mine);
+        }
         for (int spins = 0; spins < c.spin_limit; ++spins) {
             const unsigned v = tid < n ? __hip_atomic_load((ev_gu32*)(c.flags + gi + tid), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tag;
-            up = __ballot(v == tag);
-            if ((up & want) == want) break;
+            up = __ballot(v == tag) & ~taken;          // (a taken-over contributor never counts as delivered: its share is computed here)
+            const unsigned long long miss = ~up & want;
+            if (!miss || ((taken >> __builtin_ctzll(miss)) & 1ull)) break;     // all there, or the first missing one is ours to compute
             __builtin_amdgcn_s_sleep(16);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         const unsigned long long miss = ~up & want;
         const int ready = miss ? __builtin_ctzll(miss) : n;
         if (tid == 0) {
-            if (ready < n) atomicAdd(c.ctrl + 2, 1u);
+            if (ready < n) atomicAdd(c.ctrl + (((taken >> ready) & 1ull) ? 3 : 2), 1u);    // [3] shares taken over, [2] waits that ran out
             *word = ready;
         }
     }
@@ -2009,6 +2048,8 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
     auto get_tag = [&]() -> unsigned { return p.sk.ctrl ? (unsigned)__builtin_amdgcn_readfirstlane((int)tag_v) + 1u : 0u; };
     int u = sk_start(p.sk, g);
     const int ue = sk_start(p.sk, g + 1);
+    const unsigned claim_prev = sk_claim_start(p.sk, g, threadIdx.x);     // (announce this workgroup: an owner that finds it absent takes its first share over)
+    bool first_seg = true;
     const __amdgpu_buffer_rsrc_t rPart = ev_rsrc(p.sk.part), rW = ev_rsrc(p.Wh), rX = ev_rsrc(p.X);
     const unsigned pslot = (unsigned)p.sk.part_floats * 8u;
     constexpr int PN = TM * TN * 4;
@@ -2046,6 +2087,10 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
             else if (t_first < 0) dist = -t_first;
             else dist = p.S - (n0 % p.S) + p.P;
             if (dist >= BN || n0 + dist >= p.nrows) continue;
+        }
+        if (first_seg) {                                   // (only a workgroup's first segment can be a contributor's share)
+            first_seg = false;
+            if (c0 != 0 && sk_claim_taken(p.sk, claim_prev, tid, skw)) continue;     // its owner computes it: skip
         }
         if (pend_pub) { sk_publish(p.sk, g, get_tag(), tid); pend_pub = false; }
         const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
@@ -4512,6 +4557,8 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
     const unsigned tag = sk_tag(mp.sk);
     int u = sk_start(mp.sk, g);
     const int ue = sk_start(mp.sk, g + 1);
+    const unsigned claim_prev = sk_claim_start(mp.sk, g, threadIdx.x);    // (announce this workgroup: an owner that finds it absent takes its first share over)
+    bool first_seg = true;
     f32x4 R0[2], R1[2], R2[2], R3[2], R4[2], R5[2], R6[2], R7[2];
     auto ldP = [&](f32x4 (&dst)[2], int ht, int sl) {
 #pragma unroll
@@ -4561,6 +4608,10 @@ __global__ __launch_bounds__(256, 1) void ln_mlp_h16_kernel(const MlpParams mp) 
             else if (t_first < 0) dist = -t_first;
             else dist = p.S - (n0 % p.S) + p.P;
             if (dist >= NT || n0 + dist >= p.nrows) continue;
+        }
+        if (first_seg) {                               // (only a workgroup's first segment can be a contributor's share)
+            first_seg = false;
+            if (c0 != 0 && sk_claim_taken(mp.sk, claim_prev, tid, skw)) continue;    // its owner computes it: skip
         }
         {
             const int ht0 = c0 * 4 + wave;

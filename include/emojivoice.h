@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 4   /* 4: ev_dbg_set_amax; 3: ev_set_arithmetic / ev_get_arithmetic, ev_profile_read_split, test hooks; everything of earlier versions unchanged */
+#define EV_ABI_VERSION 4   /* 4: ev_dbg_set_amax, ev_dbg_sk_taken, captured decodes of many shapes; 3: ev_set_arithmetic / ev_get_arithmetic, ev_profile_read_split, test hooks; everything of earlier versions unchanged */
 
 typedef struct ev_handle ev_handle;
 
@@ -207,6 +207,10 @@ int ev_dbg_set_amax(ev_handle *h, int on);
 /* Diagnostic: the control words of the balanced ("stream-K") launches (ev_kernels.h, SkCtl) after a device synchronisation:
  * out3 = {launches so far (epoch), arrivals of an unfinished launch (0), hand-off waits that ran out and were recomputed}. */
 int ev_dbg_sk_stats(ev_handle *h, uint32_t *out3);
+/* Diagnostic (ABI 4): contributor shares the owners of balanced launches took over because the contributor had not started yet (an owner no
+ * longer waits for a workgroup that is not resident — with two pipelines in flight the vocoder holds CU slots — it computes the share itself,
+ * with the bits the contributor would have delivered), since the handle was created; -1 on error.  Synchronises the device. */
+int64_t ev_dbg_sk_taken(ev_handle *h);
 
 /* ---- operator-level entry points (unit parity tests call these) ------------------
  * Activations here are frame-major (rows, C) fp32 with an explicit row stride. */
