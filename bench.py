@@ -749,7 +749,7 @@ def main():
                                      "f32 tensors and f32 accumulation throughout; deep layers: operand = exact sum of 3 bf16 pieces, product = the piece products of "
                                      "weight <= 2 (6) / <= 1 (3); profiles/r03_bf16_split_probe.txt; parity_* below are measured on this run's timed output",
                        "batch_pipeline": "off" if pipe is None else f"cfm(i+1) || hifigan(i) on two streams, {len(pipes)} pipeline(s) in flight",
-                       "memory": "off" if pipe is None else f"{len(pipes)} engine pairs resident per GPU, each its own weights (0.3 GB: fp32 fragments + their bf16 piece planes) + workspace "
+                       "memory": "off" if pipe is None else f"{len(pipes)} engine pairs resident per GPU, each its own weights (about 0.45 GB: fp32 fragments + bf16 and fp16 piece planes in both MFMA layouts) + workspace "
                                  f"({round(model.engine.workspace_bytes(B, T, 0) / 1e9 + voc.engine.workspace_bytes(B, 0, T) / 1e9, 1)} GB at this shape)"},
             "ranks_seen": ranks_seen, "gathered_shape": gathered_shape, "per_rank_ms_per_step": per_rank_ms, "allgather_ms": allgather_ms,
             "per_gpu_audio_s_per_s": round(per_gpu, 2), "rtf": round(1.0 / per_gpu, 6), "x_realtime_per_gpu": round(per_gpu, 1),
