@@ -69,7 +69,11 @@ struct Epi {
 // c1r = block1's conv (k = 3) and res_conv (1x1, centre tap only) of one ResnetBlock1D stacked along the output axis:
 // both read the same input, so one launch stages it once; the res half's M tiles carry a one-entry tap list
 struct ResnetW { ConvLayer c1r, c2; float *g1, *b1, *g2, *b2; };
-struct TransW { ConvLayer qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln3g, *ln3b, *alpha, *binv; };
+struct TransW {
+    ConvLayer qkv, out, ff1, ff2; float *ln1g, *ln1b, *ln3g, *ln3b, *alpha, *binv;
+    // powers of two for the packed q / k / v of attn_out_h16_kernel, from bounds no input can exceed (qkv_pack_scales); 0 = not available
+    float qkv_scale[3] = {0.f, 0.f, 0.f};
+};
 
 struct EstimatorW {
     bool loaded = false;
@@ -131,6 +135,7 @@ struct ev_handle {
     bool fuse_pairs = true;     // EV_FUSE_PAIRS=0 disables resblock_pair_kernel (A/B runs)
     int fuse128 = 3;            // fuse C=128 pairs up to this kernel size (EV_FUSE128=0/3/7/11)
     bool fuse_attn = true;      // EV_FUSE_ATTN=0: attention and its output projection as separate launches (attention_kernel + a 1x1 conv)
+    bool attn_h16 = true;       // EV_NO_ATTN_H16=1: the fused attention stays on the fp32 MFMA under arithmetic setting 16 too
     bool fuse_mlp = true;       // EV_FUSE_MLP=0: LayerNorm / QKV / feed-forward of the transformer blocks as separate launches
     int gn_stats_tiles = 0;         // set by every launch_conv: row tiles whose GroupNorm statistics the launch left in Epi::gn_part (0 = none)
     int fuse_mlp_min_tiles = 96;    // EV_FUSE_MLP_MIN=<32-row tiles>: below this the separate (split-K) launches are used (measured with
@@ -1147,7 +1152,11 @@ int launch_ln(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const fl
 // (ln_mlp_kernel).  Counted as ONE conv launch of the dominant-kernel family by the profiling hooks (its FLOPs are those of
 // the linears it contains).
 int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const float* ln_b, const ConvLayer& L1, const ConvLayer* L2,
-               const float* alpha, const float* binv, const float* R, const float* rowmask, float* Y, int ldy, const Geom& g) {
+               const float* alpha, const float* binv, const float* R, const float* rowmask, float* Y, int ldy, const Geom& g,
+               const float* qkv_scale = nullptr, int* qkv_packed = nullptr) {
+    // qkv_scale (mode 1): the caller's attention can take q / k / v as fp16 piece pairs times these three powers of two; *qkv_packed tells
+    // whether this launch wrote them so (only ln_qkv_h16_kernel does)
+    if (qkv_packed) *qkv_packed = 0;
     MlpParams mp;
     memset(&mp, 0, sizeof mp);
     ConvParams& p = mp.ep;
@@ -1240,6 +1249,10 @@ int launch_mlp(ev_handle* h, int mode, const float* X, const float* ln_g, const 
         const int nt64 = (g.nrows + 63) / 64;
         if (mode == 1 && h->split_terms == 16 && !no_qkv_h16 && L1.Wh && L1.Mpad == 384 && !R && !rowmask && h->ncu > 0 && nt64 >= h->ncu) {
             mp.W1h = L1.Wh; mp.w1_scale = L1.wh_scale; mp.ntiles = nt64;
+            if (qkv_scale && qkv_packed && qkv_scale[0] > 0.f && qkv_scale[1] > 0.f && qkv_scale[2] > 0.f) {
+                mp.qkv_pack = 1; *qkv_packed = 1;
+                for (int i = 0; i < 3; ++i) mp.qkv_scale[i] = qkv_scale[i];
+            }
             const size_t smem = (size_t)64 * (4 * 256 + 16) + 32;   // (+ 8 floats: the waves' maxima and their finite-only repeat)
             hipEvent_t e0 = nullptr, e1 = nullptr;
             if (h->prof) {
@@ -1364,6 +1377,34 @@ int launch_attn(ev_handle* h, const float* QKV, int ld, float* O, int ldo, const
     return 0;
 }
 
+// The powers of two by which ln_qkv_h16_kernel scales q, k, v before it splits them into fp16 pieces.  A LayerNorm output obeys
+// |y_c| <= sqrt(C - 1) |gamma_c| + |beta_c| whatever its input (the normalised deviation of one of C numbers is at most sqrt(C - 1)), so
+// |(W y)_j| <= sum_c |W_jc| (sqrt(C - 1) |gamma_c| + |beta_c|) =: bound_j.  scale = the power of two that maps max_j bound_j into (16384, 32768]:
+// no finite input overflows fp16's 65504, and a value v keeps max(2^-22 |v|, 2^-25 / scale) — an absolute floor 2^-40 below the bound.
+// A missing or non-finite operand leaves the scales at 0: the caller keeps the fp32 form.
+void qkv_pack_scales(const HostTensor* g, const HostTensor* b, std::initializer_list<const HostTensor*> ws, float* out) {
+    out[0] = out[1] = out[2] = 0.f;
+    if (!g || !b) return;
+    float tmp[3]; int t = 0;
+    for (const HostTensor* W : ws) {
+        if (!W || W->ndim != 2 || t >= 3) return;
+        const int M = (int)W->shape[0], C = (int)W->shape[1];
+        if ((int)g->shape[0] != C || (int)b->shape[0] != C) return;
+        const double rc = std::sqrt((double)(C - 1));
+        double worst = 0.0;
+        for (int j = 0; j < M; ++j) {
+            double acc = 0.0;
+            for (int c = 0; c < C; ++c) acc += std::fabs((double)W->p[(size_t)j * C + c]) * (rc * std::fabs((double)g->p[c]) + std::fabs((double)b->p[c]));
+            worst = std::max(worst, acc);
+        }
+        if (!(worst > 0.0) || !std::isfinite(worst)) return;
+        int e = (int)std::floor(std::log2(32768.0 / worst));
+        e = std::min(40, std::max(-40, e));
+        tmp[t++] = (float)std::ldexp(1.0, e);
+    }
+    if (t == 3) for (int i = 0; i < 3; ++i) out[i] = tmp[i];
+}
+
 // attention of both heads + output projection + residual in one launch (attn_out_kernel): H += Wout . attn(QKV) + bout, in place.
 // Counted as ONE launch of the dominant-kernel family by the profiling hooks (its FLOPs: QK^T and PV of both heads + the projection).
 inline bool attn_out_ok(const ev_handle* h, const ConvLayer& Lo, const Geom& g, int H) {
@@ -1371,9 +1412,13 @@ inline bool attn_out_ok(const ev_handle* h, const ConvLayer& Lo, const Geom& g, 
     return h->fuse_attn && H == 2 && Lo.Cin == 128 && Lo.Kpad == 128 && Lo.Cout == 256 && Lo.Mpad == 256 && Lo.ntaps == 1 && !Lo.sparse_taps && Lo.bias &&
            g.S >= 4 && h->ncu > 0 && wgs >= h->ncu / 2;
 }
-int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo, float* Hid, int ldh, const float* rowmask, const Geom& g, int H) {
+// qkv_scale non-null: QKV holds fp16 piece pairs times these powers of two -> attn_out_h16_kernel
+int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo, float* Hid, int ldh, const float* rowmask, const Geom& g, int H,
+                    const float* qkv_scale = nullptr) {
     AttnOutParams p;
     memset(&p, 0, sizeof p);
+    const bool h16 = qkv_scale != nullptr;
+    if (h16) { p.inv_sq = 1.0f / qkv_scale[0]; p.inv_sk = 1.0f / qkv_scale[1]; p.inv_sv = 1.0f / qkv_scale[2]; p.Wouth = Lo.Wh; p.wo_scale = Lo.wh_scale; }
     const int B = g.nrows / g.S;
     p.QKV = QKV; p.ld = ld; p.rowmask = rowmask; p.Wout = Lo.W; p.S = g.S; p.P = g.P; p.T = g.T; p.B = B; p.nq = (g.T + 31) / 32; p.scale = 0.125f;
     p.xcd_map = (B % 8 == 0) ? 1 : 0;
@@ -1387,7 +1432,7 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
     e.nrows = g.nrows; e.S = g.S; e.P = g.P; e.T = g.T;
     if ((ldh & 3) || (ld & 3) || ((size_t)Lo.bias & 15)) return fail(h, "launch_attn_out: unaligned operand");
     if ((double)g.nrows * std::max(ld, ldh) * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
-    const size_t smem = (size_t)4 * 2 * 32 * AO_LDK * sizeof(float);
+    const size_t smem = h16 ? (size_t)4 * AOH_WB : (size_t)4 * 2 * 32 * AO_LDK * sizeof(float);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (h->prof) {
         if (h->ev_used + 2 > h->ev_pool.size()) {
@@ -1396,7 +1441,11 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
         e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
         HIPCHK(h, hipEventRecord(e0, h->stream));
     }
-    ensure_dyn_smem<attn_out_kernel>(smem, h->device);
+    if (h16) ensure_dyn_smem<attn_out_h16_kernel>(smem, h->device); else ensure_dyn_smem<attn_out_kernel>(smem, h->device);
+    auto launch = [&]() {
+        if (h16) hipLaunchKernelGGL(attn_out_h16_kernel, dim3((unsigned)(p.nq * B + (p.ntail > 0 ? B : 0))), dim3(256), smem, h->stream, p);
+        else hipLaunchKernelGGL(attn_out_kernel, dim3((unsigned)(p.nq * B + (p.ntail > 0 ? B : 0))), dim3(256), smem, h->stream, p);
+    };
     static const char* stamp_file = getenv("EV_ATTN_STAMPS");      // diagnostic: per-workgroup phase stamps of the first launches, appended to this file
     static int stamped = 0;
     const int nwg = p.nq * B + (p.ntail > 0 ? B : 0);
@@ -1405,7 +1454,7 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
         HIPCHK(h, hipMalloc((void**)&d, (size_t)nwg * 6 * sizeof(unsigned long long)));
         HIPCHK(h, hipMemsetAsync(d, 0, (size_t)nwg * 6 * sizeof(unsigned long long), h->stream));
         p.stamps = d;
-        hipLaunchKernelGGL(attn_out_kernel, dim3((unsigned)nwg), dim3(256), smem, h->stream, p);
+        launch();
         HIPCHK(h, hipStreamSynchronize(h->stream));
         std::vector<unsigned long long> st((size_t)nwg * 6);
         HIPCHK(h, hipMemcpy(st.data(), d, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1414,7 +1463,7 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
         for (int i = 0; i < nwg; ++i) t0 = std::min(t0, st[(size_t)i * 6]);
         if (FILE* f = fopen(stamp_file, "a")) {
             const char* names[6] = {"start", "first key tile", "key loop done", "merged", "projection done", "end"};
-            fprintf(f, "## attn_out_kernel T=%d B=%d: %d workgroups; us since the first workgroup started (100 MHz s_memrealtime)\n", g.T, B, nwg);
+            fprintf(f, "## %s T=%d B=%d: %d workgroups; us since the first workgroup started (100 MHz s_memrealtime)\n", h16 ? "attn_out_h16_kernel" : "attn_out_kernel", g.T, B, nwg);
             for (int k = 0; k < 6; ++k) {
                 std::vector<double> v(nwg);
                 for (int i = 0; i < nwg; ++i) v[i] = (double)(st[(size_t)i * 6 + k] - t0) / 100.0;
@@ -1437,7 +1486,7 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
         }
         ++stamped;
         p.stamps = nullptr;
-    } else hipLaunchKernelGGL(attn_out_kernel, dim3((unsigned)nwg), dim3(256), smem, h->stream, p);
+    } else launch();
     HIPCHK(h, hipGetLastError());
     if (h->prof) {
         HIPCHK(h, hipEventRecord(e1, h->stream));
@@ -1648,14 +1697,17 @@ int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z,
     // row tiles of 32 frames: the fused LayerNorm + linear kernels need about a round of workgroups to pay off (a batch-1
     // decode has 9-27 such tiles: it keeps the split-K small-launch build of the separate linears)
     const bool fuse = h->fuse_mlp && (g_rows32(L.g) >= h->fuse_mlp_min_tiles || (h->sk_spread && h->sk_balance));
+    const bool aok = attn_out_ok(h, w.out, L.g, heads);
+    int packed = 0;                                     // q / k / v left as fp16 piece pairs (ln_qkv_h16_kernel -> attn_out_h16_kernel)
     if (fuse) {
-        if (launch_mlp(h, 1, L.H, w.ln1g, w.ln1b, w.qkv, nullptr, nullptr, nullptr, nullptr, nullptr, L.QKV, 384, L.g)) return 1;
+        if (launch_mlp(h, 1, L.H, w.ln1g, w.ln1b, w.qkv, nullptr, nullptr, nullptr, nullptr, nullptr, L.QKV, 384, L.g,
+                       (aok && h->attn_h16) ? w.qkv_scale : nullptr, &packed)) return 1;
     } else {
         if (launch_ln(h, L.H, 256, L.LN, 256, w.ln1g, w.ln1b, L.g)) return 1;
         if (launch_conv(h, w.qkv, L.LN, 256, L.QKV, 384, L.g, e)) return 1;
     }
-    if (attn_out_ok(h, w.out, L.g, heads)) {
-        if (launch_attn_out(h, L.QKV, 384, w.out, L.H, 256, L.rm, L.g, heads)) return 1;   // H <- H + Wout . attn + b, one launch
+    if (aok) {
+        if (launch_attn_out(h, L.QKV, 384, w.out, L.H, 256, L.rm, L.g, heads, packed ? w.qkv_scale : nullptr)) return 1;   // H <- H + Wout . attn + b, one launch
     } else {
         if (launch_attn(h, L.QKV, 384, L.ATT, 128, L.rm, L.g, heads, L.ATTP)) return 1;
         Epi eo; eo.R = L.H; eo.ldr = 256;
@@ -1997,6 +2049,7 @@ int ev_create(ev_handle** out, int device, const ev_model_dims* dims) {
     { const char* fp = getenv("EV_FUSE128"); if (fp && *fp) h->fuse128 = atoi(fp); }
     { const char* fp = getenv("EV_FUSE_MLP"); if (fp && *fp == '0') h->fuse_mlp = false; }
     { const char* fp = getenv("EV_FUSE_ATTN"); if (fp && *fp == '0') h->fuse_attn = false; }
+    if (getenv("EV_NO_ATTN_H16")) h->attn_h16 = false;
     { const char* fp = getenv("EV_FUSE_MLP_MIN"); if (fp && *fp) h->fuse_mlp_min_tiles = atoi(fp); }
     { const char* fp = getenv("EV_MRF_STREAMS_MAX"); if (fp && *fp) h->mrf_max_frames = atoi(fp); }
     if (getenv("EV_NO_AMAX")) h->use_amax = false;
@@ -2140,6 +2193,7 @@ int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* in
         REQ(upload_vec(h, m, p + ".ff.net.0.alpha_exp", &w.tr[i].alpha));
         REQ(upload_vec(h, m, p + ".ff.net.0.beta_inv", &w.tr[i].binv));
         if (w.tr[i].qkv.Cout != 3 * h->dims.heads * 64) return fail(h, "qkv width %d != 3*heads*64", w.tr[i].qkv.Cout);
+        qkv_pack_scales(T_(p + ".norm1.weight"), T_(p + ".norm1.bias"), {q, k, v}, w.tr[i].qkv_scale);
     }
     {
         const HostTensor *d0w = T_("down_blocks.0.2.conv.weight"), *d0b = T_("down_blocks.0.2.conv.bias");
@@ -3027,12 +3081,29 @@ int ev_op_attn_out(ev_handle* h, const float* d_qkv, const int32_t* d_lengths, i
     Geom g{B * T, T, 0, T};
     float* rm = nullptr;
     if (!rc && hipMalloc((void**)&rm, (size_t)g.nrows * 4) != hipSuccess) rc = fail(h, "ev_op_attn_out: out of memory");
+    float* packed = nullptr;
+    float sc[3] = {0.f, 0.f, 0.f};
+    if (!rc && h->split_terms == 16 && h->attn_h16) {
+        // arithmetic setting 16: the op runs what the model runs — q / k / v as fp16 piece pairs (the model's ln_qkv_h16_kernel writes them so;
+        // here a copy is packed, with scales from the data's own maxima where the loader uses its weight bound) and attn_out_h16_kernel
+        std::vector<float> hq((size_t)g.nrows * 384);
+        if (hipMemcpy(hq.data(), d_qkv, hq.size() * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(h, "ev_op_attn_out: copy failed");
+        float mx[3] = {0.f, 0.f, 0.f};
+        for (size_t i = 0; i < hq.size(); ++i) { const float a = std::fabs(hq[i]); if (std::isfinite(a)) { float& m = mx[(i % 384) / 128]; m = std::max(m, a); } }
+        for (int i = 0; i < 3; ++i) sc[i] = mx[i] > 0.f ? (float)std::ldexp(1.0, std::min(40, std::max(-40, (int)std::floor(std::log2(32768.0 / mx[i]))))) : 1.f;
+        if (!rc && hipMalloc((void**)&packed, hq.size() * 4) != hipSuccess) rc = fail(h, "ev_op_attn_out: out of memory");
+        if (!rc) {
+            const size_t npairs = hq.size() / 2;
+            hipLaunchKernelGGL(qkv_pack_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, h->stream, d_qkv, packed, npairs, sc[0], sc[1], sc[2]);
+        }
+    }
     if (!rc) {
         hipLaunchKernelGGL(rowmask_kernel, dim3((g.nrows + 255) / 256), dim3(256), 0, h->stream, rm, d_lengths, g.nrows, g.S, g.P, g.T, 1);
-        rc = launch_attn_out(h, d_qkv, 384, Lo, d_hid, 256, rm, g, 2);
+        rc = launch_attn_out(h, packed ? packed : d_qkv, 384, Lo, d_hid, 256, rm, g, 2, packed ? sc : nullptr);
     }
     if (hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(h, "sync failed");
     if (rm) hipFree(rm);
+    if (packed) hipFree(packed);
     while (h->owned.size() > owned0) {
         if (h->owned.back() == (void*)h->zeros) break;
         hipFree(h->owned.back()); h->owned.pop_back();

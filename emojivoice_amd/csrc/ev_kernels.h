@@ -3854,6 +3854,7 @@ struct MlpParams {
     const void* W1x; const void* W2x;                // ln_mlp_split_kernel: both linears as three bf16 pieces (conv_split_kernel's fragment order)
     int ntiles;                    // 32-row tiles of the launch; the grid is either ntiles workgroups (one tile each: sk.q = M1 / 128,
     SkCtl sk;                      // sk.r = 0, no hand-offs) or the balanced persistent grid described at SkCtl
+    int qkv_pack; float qkv_scale[3];   // ln_qkv_h16_kernel: write q / k / v as fp16 piece pairs (see attn_out_h16_kernel), times these powers of two
 };
 
 // unit = (32-row tile, 128-wide chunk of the hidden [MODE 1: output] width); a workgroup walks its unit range tile segment by tile
@@ -5057,12 +5058,33 @@ __global__ __launch_bounds__(256, 2) void ln_qkv_h16_kernel(const MlpParams mp) 
         // in every slab: the K loop then takes 10.5 us instead of 5, profiles/r03_ln_qkv_h16_stamps.txt)
         __builtin_amdgcn_sched_barrier(0);
     }
+    if (!mp.qkv_pack) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv1;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv1;
+    } else {
+        // The packed form attn_out_h16_kernel consumes: every value times its tensor's power-of-two scale (q, k, v: channel tiles 0-3, 4-7,
+        // 8-11) as two fp16 pieces, IN PLACE of the fp32 words: the lane holds channels c, c + 1 (c even) in registers 2u, 2u + 1, and leaves
+        // word c = (hi c, hi c+1), word c + 1 = (lo c, lo c+1).  Same row layout and bytes as the fp32 tensor; the lean epilogue only moves words.
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const float f = inv1 * mp.qkv_scale[(wave * TM + i) >> 2];      // (both powers of two)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float c0 = acc[i][j][2 * u] * f, c1 = acc[i][j][2 * u + 1] * f;
+                    const _Float16 h0 = (_Float16)c0, h1 = (_Float16)c1;
+                    const _Float16 l0 = (_Float16)(c0 - (float)h0), l1 = (_Float16)(c1 - (float)h1);
+                    const f16x2 hh = {h0, h1}, ll = {l0, l1};
+                    acc[i][j][2 * u] = __builtin_bit_cast(float, hh);
+                    acc[i][j][2 * u + 1] = __builtin_bit_cast(float, ll);
+                }
+        }
+    }
     stamp(3);
     // ---- store (the epilogue's first barrier retires the K loop's LDS reads; its slabs lie in the dead X planes)
     {
@@ -5244,7 +5266,21 @@ struct AttnOutParams {
                                 // 4 x 4 MFMA blocks (blocks 0 .. B-1 of the grid, dispatched first): see attn_tail_path
     float scale; int xcd_map;   // xcd_map: B % 8 == 0 -> the tiles of an utterance share an XCD (its K / V stay in that XCD's L2)
     unsigned long long* stamps; // diagnostic (EV_ATTN_STAMPS): six s_memrealtime stamps per workgroup, or null
+    // attn_out_h16_kernel: QKV holds fp16 piece pairs times the powers of two sq / sk / sv (ln_qkv_h16_kernel, qkv_pack)
+    float inv_sq, inv_sk, inv_sv;
+    const void* Wouth; float wo_scale;   // the projection as two fp16 pieces in conv_h16_kernel's fragment order, times wo_scale
 };
+// one packed word pair -> two fp32 values: words (hi c, hi c+1), (lo c, lo c+1)
+__device__ __forceinline__ void ev_unpack_pair(float w_hi, float w_lo, float inv, float& a, float& b) {
+    const f16x2 hh = __builtin_bit_cast(f16x2, w_hi), ll = __builtin_bit_cast(f16x2, w_lo);
+    a = ((float)hh[0] + (float)ll[0]) * inv; b = ((float)hh[1] + (float)ll[1]) * inv;
+}
+__device__ __forceinline__ f32x4 ev_unpack4(const f32x4 w, float inv) {
+    float a, b, c, d;
+    ev_unpack_pair(w[0], w[1], inv, a, b); ev_unpack_pair(w[2], w[3], inv, c, d);
+    const f32x4 r = {a, b, c, d};
+    return r;
+}
 
 #define AO_LDK 68
 #define AO_OLD 132
@@ -5263,6 +5299,7 @@ struct AttnOutParams {
 //   P . V:   block = 4 dims;  A = P[query x][key] (every block the same: gathered with ds_bpermute from the score layout),
 //            B = V[key][lane]  ->  D reg i = O[query i][dim lane]
 // Same (head, key half) waves, wave-private K / V tiles, merge of the key halves and projection (one output channel per thread here).
+template <bool PK = false>   // PK: QKV in the packed fp16-pair form (decoded where it is staged: this path stays on the fp32 4 x 4 blocks)
 __device__ __forceinline__ void attn_tail_path(const AttnOutParams& p, int b, float* smem, int tid, int lane, int wave) {
     const int x = lane & 3, dh = (lane >> 2) & 1, kg = lane >> 3, li = lane & 31, h = wave & 1, kh = wave >> 1;
     const int NT = p.ntail;
@@ -5280,7 +5317,10 @@ __device__ __forceinline__ void attn_tail_path(const AttnOutParams& p, int b, fl
         const unsigned off = (rowbase + (unsigned)(ok ? q0 + x : 0)) * ldb + (unsigned)(h * 64 + 32 * dh) * 4u;
         const float qs = ok ? p.scale * L2E : 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) qv[i] = ev_bload4(rQ, off + (unsigned)(4 * i) * 4u, 0) * qs;
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 w = ev_bload4(rQ, off + (unsigned)(4 * i) * 4u, 0);
+            qv[i] = (PK ? ev_unpack4(w, p.inv_sq) : w) * qs;
+        }
     }
     const int nkt = (p.T + 31) / 32, nh0 = (nkt + 1) / 2;
     const int kt0 = kh ? nh0 : 0, kt1 = kh ? nkt : nh0;
@@ -5309,8 +5349,8 @@ __device__ __forceinline__ void attn_tail_path(const AttnOutParams& p, int b, fl
     for (int kt = kt0; kt < kt1; ++kt) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            *(f32x4*)(Ks + (4 * j + srow) * AO_LDK + sc4) = kr[j];
-            *(f32x4*)(Vs + (4 * j + srow) * AO_LDK + sc4) = vr[j];
+            *(f32x4*)(Ks + (4 * j + srow) * AO_LDK + sc4) = PK ? ev_unpack4(kr[j], p.inv_sk) : kr[j];
+            *(f32x4*)(Vs + (4 * j + srow) * AO_LDK + sc4) = PK ? ev_unpack4(vr[j], p.inv_sv) : vr[j];
         }
         const f32x4 mkey = mk4;
         kv_issue(kt + 1 < kt1 ? kt + 1 : kt);
@@ -5601,6 +5641,242 @@ __global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p)
 }
 
 // ---------------------------------------------------------------------------
+// attn_out_h16_kernel: attn_out_kernel on the fp16 matrix pipe (round 4).  Same workgroup (one 32-query tile, waves = (head, key half),
+// wave-private K / V tiles, no barrier in the key loop), same merge, projection and epilogue; the two products of the key loop run on
+// v_mfma_f32_32x32x16_f16 over operands that are fp16 PIECE PAIRS written by the producer (ln_qkv_h16_kernel, qkv_pack): every q / k / v
+// value x is stored, in place of its fp32 word pair, as x s = hi + lo (hi = nearest fp16, lo = nearest fp16 of the rest: 22 significand bits)
+// with a power-of-two s per tensor that the LOADER derives from a bound no input can exceed (|LayerNorm(x)_c| <= sqrt(C - 1)|gamma_c| + |beta_c|,
+// so |k_j| <= sum_c |W_jc| (...)): s maps the bound to (16384, 32768], nothing overflows, and values far below the bound keep an ABSOLUTE
+// precision of 2^-25 / s = 2^-40 of the bound.  A row of the packed tensor reads, per four fp16 columns, (hi c, hi c+1, lo c, lo c+1), c even.
+//   scores: S^T[key][q] = sum_d (hK + lK)(hQ + lQ).  A = 16 bytes of the key's row as they lie = (hK0 hK1 lK0 lK1 hK2 hK3 lK2 lK3): four dims, both
+//           pieces; B1 = (hQ0 hQ1 hQ0 hQ1 hQ2 hQ3 hQ2 hQ3), B2 = the same of lQ: two MFMAs per four dims x two lane halves = ALL FOUR piece products
+//           (16 MFMAs per 32-key tile for 64 dims; the three-product form would need 12 plus a re-arrangement of K in the vector ALUs).
+//   P . V:  O^T[column][q] += sum_key V[key][column] P[q][key] over the 128 fp16 COLUMNS of V's row (both pieces of 64 dims: four M tiles); the A
+//           operand is the transposed read ds_read_b64_tr_b16 of the V tile as it lies (row stride 320 B: four keys' 64-byte blocks on disjoint
+//           banks), the B operands are hP and lP straight from the score registers — P' = 2^13 exp2(s - m) <= 8192 as two pieces — whose key
+//           order (register r of lane half lh = key (r & 3) + 8 (r >> 2) + 4 lh) the transposed reads follow.  O[dim] = the hi column's row + the
+//           lo column's row, both in one lane (registers 4a + e and 4a + 2 + e): added once after the key loop.
+// Neither tile passes through the vector ALUs: global -> registers -> LDS as bytes.  The frame mask is added with the scale in one FMA per score.
+// Arithmetic: all piece products of 22-bit operands, fp32 accumulation — the class of the convolutions' setting 16.
+// ---------------------------------------------------------------------------
+typedef short ev_v4s __attribute__((__vector_size__(4 * sizeof(short))));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define AOH_KRS 272
+#define AOH_VRS 320
+#define AOH_WB (32 * AOH_KRS + 32 * AOH_VRS + 256)     // a wave's K tile, V tile, 32 mask values (19200 bytes; four waves, two workgroups per CU: 150 KB)
+__global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int h = wave & 1, kh = wave >> 1;
+    int b, qt;
+    {
+        int id = blockIdx.x;
+        const int ntw = p.ntail > 0 ? p.B : 0;         // the short last tiles first, on the fp32 4 x 4 blocks (attn_tail_path decodes the pairs)
+        if (id < ntw) {
+            if (p.stamps && tid == 0) p.stamps[6 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+            attn_tail_path<true>(p, p.xcd_map ? (id & 7) + 8 * (id >> 3) : id, smem, tid, lane, wave);
+            if (p.stamps && tid == 0) { const unsigned long long t = __builtin_amdgcn_s_memrealtime(); for (int k = 1; k < 6; ++k) p.stamps[6 * blockIdx.x + k] = t; }
+            return;
+        }
+        id -= ntw;
+        if (p.xcd_map) { const int within = id >> 3; qt = within % p.nq; b = (id & 7) + 8 * (within / p.nq); }
+        else { b = id / p.nq; qt = id - b * p.nq; }
+    }
+    const int q0 = qt * 32;
+    const unsigned rowbase = (unsigned)b * p.S + p.P;
+    auto stamp = [&](int k) { if (p.stamps && tid == 0) p.stamps[6 * blockIdx.x + k] = __builtin_amdgcn_s_memrealtime(); };
+    stamp(0);
+    char* Kt = (char*)smem + wave * AOH_WB;            // [32 keys][AOH_KRS]: the key rows of head h as they lie in the packed tensor
+    char* Vt = Kt + 32 * AOH_KRS;                      // [32 keys][AOH_VRS]
+    float* Mt = (float*)(Vt + 32 * AOH_VRS);           // [32] additive masks of the tile's keys, log2 domain
+    const __amdgpu_buffer_rsrc_t rQ = ev_rsrc(p.QKV), rM = ev_rsrc(p.rowmask), rW = ev_rsrc(p.Wout);
+    const float L2E = 1.44269504088896340736f;
+    const unsigned ldb = (unsigned)p.ld * 4u;
+    const int nkt = (p.T + 31) / 32, nh0 = (nkt + 1) / 2;
+    const int kt0 = kh ? nh0 : 0, kt1 = kh ? nkt : nh0;
+    // staging: float4 j of this lane = (key row 4j + lane/16, words 4 (lane % 16) ..): a load instruction covers 4 rows x 256 B
+    f32x4 kr[8], vr[8];
+    float mk = 0.f;
+    const int srow = lane >> 4, sc4 = (lane & 15) * 4;
+    const unsigned kcol = (unsigned)(128 + h * 64 + sc4) * 4u, vcol = (unsigned)(256 + h * 64 + sc4) * 4u;
+    auto kv_issue = [&](int kt) {      // every load unconditional: keys beyond the utterance re-read its last frame and are masked out
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int tk = kt * 32 + 4 * j + srow;
+            const unsigned ro = (rowbase + (unsigned)(tk < p.T ? tk : p.T - 1)) * ldb;
+            kr[j] = ev_bload4(rQ, ro + kcol, 0);
+            vr[j] = ev_bload4(rQ, ro + vcol, 0);
+        }
+        const int tm = kt * 32 + li;
+        const float m = ev_bload1(rM, (rowbase + (unsigned)(tm < p.T ? tm : p.T - 1)) * 4u, 0);
+        mk = tm < p.T ? m * L2E : -1e30f;
+    };
+    if (kt0 < kt1) kv_issue(kt0);
+    // Q operands: lane (query li, half lh), step g = dims 8g + 4lh .. + 3 = words (h01, l01, h23, l23) of the packed row
+    f32x4 qb1[8], qb2[8];
+    {
+        const int tq = q0 + li;
+        const unsigned off = (rowbase + (unsigned)(tq < p.T ? tq : 0)) * ldb + (unsigned)(h * 64 + 4 * lh) * 4u;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f32x4 w = ev_bload4(rQ, off + (unsigned)(8 * g) * 4u, 0);
+            const f32x4 b1 = {w[0], w[0], w[2], w[2]}, b2 = {w[1], w[1], w[3], w[3]};
+            qb1[g] = b1; qb2[g] = b2;
+        }
+    }
+    const float q_unit = p.scale * L2E * p.inv_sq * p.inv_sk;       // accumulator units -> log2-domain scores
+    f32x16 o[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[m][r] = 0.f;
+    float mrun = -1e30f, lrun = 0.f;
+    // transposed reads: lane 4q + pp of the 16-lane group g16 supplies (key 4 (g16 >> 1) + q [+ 16 step + 8 e4], columns 16 (g16 & 1) + 4 pp .. [+ 32 mt])
+    const __attribute__((address_space(3))) char* vtr = (const __attribute__((address_space(3))) char*)(Vt + (4 * (lane >> 5) + ((lane >> 2) & 3)) * AOH_VRS +
+                                                                                                       2 * (16 * ((lane >> 4) & 1) + 4 * (lane & 3)));
+    const char* krow = Kt + li * AOH_KRS + 16 * lh;
+    for (int kt = kt0; kt < kt1; ++kt) {
+        if (kt == kt0 + 1) stamp(1);
+        // publish the prefetched tile to this wave's LDS (the wave's LDS operations execute in order: no barrier, no other reader)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            *(f32x4*)(Kt + (4 * j + srow) * AOH_KRS + sc4 * 4) = kr[j];
+            *(f32x4*)(Vt + (4 * j + srow) * AOH_VRS + sc4 * 4) = vr[j];
+        }
+        Mt[li] = mk;
+        kv_issue(kt + 1 < kt1 ? kt + 1 : kt);          // next tile (after the last: a harmless re-read)
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const f16x8 a = __builtin_bit_cast(f16x8, *(const f32x4*)(krow + 32 * g));
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, qb1[g]), s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, qb2[g]), s, 0, 0, 0);
+        }
+        float mx = -1e30f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const f32x4 m4 = *(const f32x4*)(Mt + 8 * a + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[4 * a + e] = fmaf(s[4 * a + e], q_unit, m4[e]); mx = fmaxf(mx, s[4 * a + e]); }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun, mx);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        const float msub = mnew - 13.f;                 // P' = 2^13 P: the pieces of small probabilities keep their bits
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - msub); ps += s[r]; }
+        ps += __shfl_xor(ps, 32, 64);
+        lrun = lrun * alpha + ps;
+        mrun = mnew;
+        f16x8 ph[2], pl[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const _Float16 hh = (_Float16)s[r];
+            ph[r >> 3][r & 7] = hh;
+            pl[r >> 3][r & 7] = (_Float16)(s[r] - (float)hh);
+        }
+        if (!__all(alpha == 1.0f)) {                   // (wave-uniform: the running maximum of most tiles after the first few is old)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const ev_v4s t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ev_v4s*)(vtr + (16 * st) * AOH_VRS + 64 * m));
+                const ev_v4s t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ev_v4s*)(vtr + (16 * st + 8) * AOH_VRS + 64 * m));
+                const s16x8 av = {t0[0], t0[1], t0[2], t0[3], t1[0], t1[1], t1[2], t1[3]};
+                const f16x8 a = __builtin_bit_cast(f16x8, av);
+                o[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ph[st], o[m], 0, 0, 0);
+                o[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pl[st], o[m], 0, 0, 0);
+            }
+    }
+    stamp(2);
+    // hi column row + lo column row: od[m][a] = dims 16 m + 4 a + 2 lh + (0, 1) of query li, un-normalised, in units of 2^13 sv
+    float od[4][4][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { od[m][a][0] = o[m][4 * a] + o[m][4 * a + 2]; od[m][a][1] = o[m][4 * a + 1] + o[m][4 * a + 3]; }
+    // ---- first weight fragments of the projection, into the staging registers: they land while the key halves are merged
+    const unsigned wlane = (unsigned)lane * 16u;
+    auto ldW = [&](int a, int kg) { return ev_bload4(rW, wlane, (unsigned)((wave * 2 + a) * 16 + kg) * 1024u); };
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kr[j] = ldW(0, j); vr[j] = ldW(1, j); }
+    // ---- merge the two key halves of each head through the (now dead) region of wave (h, 1); normalised rows into Os[query][128]
+    // inside wave 0's region
+    float* Os = smem;                                  // [32][AO_OLD]
+    float* Pw = (float*)Kt;                            // wave (h, 1): [8 float4 slots][64 lanes], then m and l
+    ev_lds_barrier();                                  // every wave has left its key loop
+    if (kh == 1) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2) {
+                const f32x4 v = {od[m][2 * a2][0], od[m][2 * a2][1], od[m][2 * a2 + 1][0], od[m][2 * a2 + 1][1]};
+                *(f32x4*)(Pw + ((m * 2 + a2) * 64 + lane) * 4) = v;
+            }
+        Pw[8 * 256 + lane] = mrun;
+        Pw[8 * 256 + 64 + lane] = lrun;
+    }
+    ev_lds_barrier();
+    if (kh == 0) {
+        const float* Ps = (const float*)((const char*)smem + (wave + 2) * AOH_WB);       // region of wave (h, 1)
+        const float m1 = Ps[8 * 256 + lane], l1 = Ps[8 * 256 + 64 + lane];
+        const float mm = fmaxf(mrun, m1);
+        const float a0 = __builtin_amdgcn_exp2f(mrun - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
+        const float inv = p.inv_sv / (lrun * a0 + l1 * a1);        // (the 2^13 of P' cancels between O and l)
+        const float w0 = a0 * inv, w1 = a1 * inv;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2) {
+                const f32x4 pv = *(const f32x4*)(Ps + ((m * 2 + a2) * 64 + lane) * 4);
+                const float2 x0 = {od[m][2 * a2][0] * w0 + pv[0] * w1, od[m][2 * a2][1] * w0 + pv[1] * w1};
+                const float2 x1 = {od[m][2 * a2 + 1][0] * w0 + pv[2] * w1, od[m][2 * a2 + 1][1] * w0 + pv[3] * w1};
+                *(float2*)(Os + li * AO_OLD + h * 64 + 16 * m + 8 * a2 + 2 * lh) = x0;
+                *(float2*)(Os + li * AO_OLD + h * 64 + 16 * m + 8 * a2 + 4 + 2 * lh) = x1;
+            }
+    }
+    ev_lds_barrier();
+    stamp(3);
+    // ---- projection: Y^T[256][32] = Wout . O^T, K = 128 = 16 k-groups; bias preloaded into the accumulators (lean epilogue convention)
+    f32x16 acc[2][1];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            if (p.ep.bias) bq = *(const f32x4*)(p.ep.bias + wave * 64 + a * 32 + 8 * q + 4 * lh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[a][0][4 * q + e] = bq[e];
+        }
+    const float* orow = Os + li * AO_OLD + 4 * lh;
+#pragma unroll
+    for (int kg = 0; kg < 16; ++kg) {
+        const f32x4 bfr = *(const f32x4*)(orow + kg * 8);
+        const f32x4 fa = kr[kg & 7], fb = vr[kg & 7];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], bfr[e], acc[0][0], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[e], bfr[e], acc[1][0], 0, 0, 0);
+        }
+        if (kg < 8) { kr[kg] = ldW(0, kg + 8); vr[kg] = ldW(1, kg + 8); }
+    }
+    stamp(4);
+    // ---- + residual rows, store (rows of THIS utterance only: a tile's tail rows may belong to the next one)
+    conv_epilogue_lean<2, 1, 1>(p.ep, acc, smem + wave * (32 * 68), wave * 64, (int)rowbase + q0, lane, (int)rowbase, (int)rowbase + p.T);
+    stamp(5);
+}
+
+// ---------------------------------------------------------------------------
 // attention_part_kernel + attention_merge_kernel: the small-launch build of attention_kernel.  A batch-1 decode has 6-10
 // workgroups per attention launch, and each of their waves is a serial chain over all 9-17 key tiles: 64 MFMAs = 1.7 us of its
 // SIMD's matrix pipe per tile, i.e. the launch is bound by the pipes of the handful of CUs it runs on (27-48 us, 60 launches
@@ -5752,6 +6028,18 @@ __global__ __launch_bounds__(256) void attention_merge_kernel(const AttnPartPara
 // Layout / elementwise helpers
 // ---------------------------------------------------------------------------
 // rowmask[n] = 1 if 0 <= t < ceil(len[b] / sub) (sub = 1: level-0 mask; sub = 2: mask[:, :, ::2]), else 0
+// fp32 (rows, 384) q | k | v -> the packed fp16-pair form of ln_qkv_h16_kernel (qkv_pack), for callers that hold an fp32 tensor (ev_op_attn_out)
+__global__ void qkv_pack_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t npairs, float s0, float s1, float s2) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    const int c = (int)(i % 192) * 2;
+    const float sc = c < 128 ? s0 : (c < 256 ? s1 : s2);
+    const float c0 = src[2 * i] * sc, c1 = src[2 * i + 1] * sc;
+    const _Float16 h0 = (_Float16)c0, h1 = (_Float16)c1;
+    const f16x2 hh = {h0, h1}, ll = {(_Float16)(c0 - (float)h0), (_Float16)(c1 - (float)h1)};
+    dst[2 * i] = __builtin_bit_cast(float, hh);
+    dst[2 * i + 1] = __builtin_bit_cast(float, ll);
+}
 __global__ void rowmask_kernel(float* m, const int32_t* lengths, int nrows, int S, int P, int T, int sub) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= nrows) return;
