@@ -1701,7 +1701,7 @@ int run_transformer(ev_handle* h, const TransW& w, const LevelBufs& L, float* Z,
     int packed = 0;                                     // q / k / v left as fp16 piece pairs (ln_qkv_h16_kernel -> attn_out_h16_kernel)
     if (fuse) {
         if (launch_mlp(h, 1, L.H, w.ln1g, w.ln1b, w.qkv, nullptr, nullptr, nullptr, nullptr, nullptr, L.QKV, 384, L.g,
-                       (aok && h->attn_h16) ? w.qkv_scale : nullptr, &packed)) return 1;
+                       (aok && h->attn_h16 && w.out.Wh) ? w.qkv_scale : nullptr, &packed)) return 1;
     } else {
         if (launch_ln(h, L.H, 256, L.LN, 256, w.ln1g, w.ln1b, L.g)) return 1;
         if (launch_conv(h, w.qkv, L.LN, 256, L.QKV, 384, L.g, e)) return 1;
@@ -2818,6 +2818,14 @@ int ev_dbg_set_amax(ev_handle* h, int on) {
     return 0;
 }
 
+// Diagnostic / A-B switch (ABI v4): 1 (default) = under arithmetic setting 16 the fused attention runs on the fp16 pipe (attn_out_h16_kernel, q / k / v
+// left as fp16 piece pairs by ln_qkv_h16_kernel), 0 = it stays on the fp32 MFMA (attn_out_kernel).  EV_NO_ATTN_H16=1 presets 0.
+int ev_dbg_set_attn_h16(ev_handle* h, int on) {
+    if (!h) return 1;
+    h->attn_h16 = on != 0;
+    return 0;
+}
+
 // The launches of the bf16-split builds (conv_split_kernel, conv_split_bal_kernel, resblock_pair_split_kernel) among those recorded
 // since the last reset: call before ev_profile_read(..., reset = 1).
 int ev_profile_read_split(ev_handle* h, double* ms_out, double* flops_out, int64_t* launches_out) {
@@ -3083,7 +3091,7 @@ int ev_op_attn_out(ev_handle* h, const float* d_qkv, const int32_t* d_lengths, i
     if (!rc && hipMalloc((void**)&rm, (size_t)g.nrows * 4) != hipSuccess) rc = fail(h, "ev_op_attn_out: out of memory");
     float* packed = nullptr;
     float sc[3] = {0.f, 0.f, 0.f};
-    if (!rc && h->split_terms == 16 && h->attn_h16) {
+    if (!rc && h->split_terms == 16 && h->attn_h16 && Lo.Wh) {
         // arithmetic setting 16: the op runs what the model runs — q / k / v as fp16 piece pairs (the model's ln_qkv_h16_kernel writes them so;
         // here a copy is packed, with scales from the data's own maxima where the loader uses its weight bound) and attn_out_h16_kernel
         std::vector<float> hq((size_t)g.nrows * 384);

@@ -5691,7 +5691,7 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
     char* Kt = (char*)smem + wave * AOH_WB;            // [32 keys][AOH_KRS]: the key rows of head h as they lie in the packed tensor
     char* Vt = Kt + 32 * AOH_KRS;                      // [32 keys][AOH_VRS]
     float* Mt = (float*)(Vt + 32 * AOH_VRS);           // [32] additive masks of the tile's keys, log2 domain
-    const __amdgpu_buffer_rsrc_t rQ = ev_rsrc(p.QKV), rM = ev_rsrc(p.rowmask), rW = ev_rsrc(p.Wout);
+    const __amdgpu_buffer_rsrc_t rQ = ev_rsrc(p.QKV), rM = ev_rsrc(p.rowmask), rW = ev_rsrc(p.Wouth);
     const float L2E = 1.44269504088896340736f;
     const unsigned ldb = (unsigned)p.ld * 4u;
     const int nkt = (p.T + 31) / 32, nh0 = (nkt + 1) / 2;
@@ -5805,14 +5805,20 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int a = 0; a < 4; ++a) { od[m][a][0] = o[m][4 * a] + o[m][4 * a + 2]; od[m][a][1] = o[m][4 * a + 1] + o[m][4 * a + 3]; }
-    // ---- first weight fragments of the projection, into the staging registers: they land while the key halves are merged
+    // ---- first weight fragments of the projection (two fp16 pieces, conv_h16_kernel's fragment order: row tile 2 wave + a, 16-deep step ks, piece pc
+    // at (((2 wave + a) 8 + ks) 2 + pc) KiB), into the staging registers: they land while the key halves are merged.  Ring slot of (a, ks, pc) =
+    // kr / vr [4 (ks & 1) + 2 a + pc] for even / odd ks >> 1 ... i.e. steps 0-3 now, steps 4-7 as their slots come free.
     const unsigned wlane = (unsigned)lane * 16u;
-    auto ldW = [&](int a, int kg) { return ev_bload4(rW, wlane, (unsigned)((wave * 2 + a) * 16 + kg) * 1024u); };
+    auto ldW = [&](int a, int ks, int pc) { return ev_bload4(rW, wlane, (unsigned)((((wave * 2 + a) * 8 + ks) * 2 + pc) * 1024)); };
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { kr[j] = ldW(0, j); vr[j] = ldW(1, j); }
-    // ---- merge the two key halves of each head through the (now dead) region of wave (h, 1); normalised rows into Os[query][128]
-    // inside wave 0's region
-    float* Os = smem;                                  // [32][AO_OLD]
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) { kr[4 * ks + 2 * a + pc] = ldW(a, ks, pc); vr[4 * ks + 2 * a + pc] = ldW(a, ks + 2, pc); }
+    // ---- merge the two key halves of each head through the (now dead) region of wave (h, 1); normalised rows — in units of sv: |O| <= max |v|,
+    // so v's scale fits — as two fp16 planes into Os[query][hi 128 | lo 128] (row stride 528 B = AO_OLD words) inside wave 0's region
+    char* Os = (char*)smem;
     float* Pw = (float*)Kt;                            // wave (h, 1): [8 float4 slots][64 lanes], then m and l
     ev_lds_barrier();                                  // every wave has left its key loop
     if (kh == 1) {
@@ -5832,22 +5838,27 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
         const float m1 = Ps[8 * 256 + lane], l1 = Ps[8 * 256 + 64 + lane];
         const float mm = fmaxf(mrun, m1);
         const float a0 = __builtin_amdgcn_exp2f(mrun - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
-        const float inv = p.inv_sv / (lrun * a0 + l1 * a1);        // (the 2^13 of P' cancels between O and l)
+        const float inv = 1.0f / (lrun * a0 + l1 * a1);           // (the 2^13 of P' cancels between O and l; sv stays: see above)
         const float w0 = a0 * inv, w1 = a1 * inv;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int a2 = 0; a2 < 2; ++a2) {
                 const f32x4 pv = *(const f32x4*)(Ps + ((m * 2 + a2) * 64 + lane) * 4);
-                const float2 x0 = {od[m][2 * a2][0] * w0 + pv[0] * w1, od[m][2 * a2][1] * w0 + pv[1] * w1};
-                const float2 x1 = {od[m][2 * a2 + 1][0] * w0 + pv[2] * w1, od[m][2 * a2 + 1][1] * w0 + pv[3] * w1};
-                *(float2*)(Os + li * AO_OLD + h * 64 + 16 * m + 8 * a2 + 2 * lh) = x0;
-                *(float2*)(Os + li * AO_OLD + h * 64 + 16 * m + 8 * a2 + 4 + 2 * lh) = x1;
+                const f32x4 x = {od[m][2 * a2][0] * w0 + pv[0] * w1, od[m][2 * a2][1] * w0 + pv[1] * w1,
+                                 od[m][2 * a2 + 1][0] * w0 + pv[2] * w1, od[m][2 * a2 + 1][1] * w0 + pv[3] * w1};
+                uint2 q0v, q1v;                         // (hi x0 x1 | hi x2 x3), (lo ...): dims d, d + 1 and d + 4, d + 5, d = 64 h + 16 m + 8 a2 + 2 lh
+                evh_split4(x, q0v, q1v);
+                char* dst = Os + li * (AO_OLD * 4) + 2 * (h * 64 + 16 * m + 8 * a2 + 2 * lh);
+                *(unsigned*)(dst) = q0v.x; *(unsigned*)(dst + 8) = q0v.y;
+                *(unsigned*)(dst + 256) = q1v.x; *(unsigned*)(dst + 256 + 8) = q1v.y;
             }
     }
     ev_lds_barrier();
     stamp(3);
-    // ---- projection: Y^T[256][32] = Wout . O^T, K = 128 = 16 k-groups; bias preloaded into the accumulators (lean epilogue convention)
+    // ---- projection: Y^T[256][32] = Wout . O^T, K = 128 = 8 steps of 16, three piece products; accumulators in units of wo_scale sv,
+    // bias preloaded (lean epilogue convention)
+    const float u = p.wo_scale / p.inv_sv, inv_u = 1.0f / u;
     f32x16 acc[2][1];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -5856,20 +5867,32 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
             f32x4 bq = {0.f, 0.f, 0.f, 0.f};
             if (p.ep.bias) bq = *(const f32x4*)(p.ep.bias + wave * 64 + a * 32 + 8 * q + 4 * lh);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[a][0][4 * q + e] = bq[e];
+            for (int e = 0; e < 4; ++e) acc[a][0][4 * q + e] = bq[e] * u;
         }
-    const float* orow = Os + li * AO_OLD + 4 * lh;
+    const char* orow = Os + li * (AO_OLD * 4) + 16 * lh;
 #pragma unroll
-    for (int kg = 0; kg < 16; ++kg) {
-        const f32x4 bfr = *(const f32x4*)(orow + kg * 8);
-        const f32x4 fa = kr[kg & 7], fb = vr[kg & 7];
+    for (int ks = 0; ks < 8; ++ks) {
+        const f16x8 bh = __builtin_bit_cast(f16x8, *(const f32x4*)(orow + 32 * ks)), bl = __builtin_bit_cast(f16x8, *(const f32x4*)(orow + 256 + 32 * ks));
+        f32x4 (&ring)[8] = (ks & 2) ? vr : kr;
+        const int s4 = 4 * (ks & 1);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], bfr[e], acc[0][0], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fb[e], bfr[e], acc[1][0], 0, 0, 0);
+        for (int a = 0; a < 2; ++a) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, ring[s4 + 2 * a]), al = __builtin_bit_cast(f16x8, ring[s4 + 2 * a + 1]);
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[a][0], 0, 0, 0);
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[a][0], 0, 0, 0);
+            acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[a][0], 0, 0, 0);
         }
-        if (kg < 8) { kr[kg] = ldW(0, kg + 8); vr[kg] = ldW(1, kg + 8); }
+        if (ks < 4) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) ring[s4 + 2 * a + pc] = ldW(a, ks + 4, pc);
+        }
     }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][0][r] *= inv_u;
     stamp(4);
     // ---- + residual rows, store (rows of THIS utterance only: a tile's tail rows may belong to the next one)
     conv_epilogue_lean<2, 1, 1>(p.ep, acc, smem + wave * (32 * 68), wave * 64, (int)rowbase + q0, lane, (int)rowbase, (int)rowbase + p.T);

@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 4   /* 4: ev_dbg_set_amax, ev_dbg_sk_taken, captured decodes of many shapes; 3: ev_set_arithmetic / ev_get_arithmetic, ev_profile_read_split, test hooks; everything of earlier versions unchanged */
+#define EV_ABI_VERSION 4   /* 4: ev_dbg_set_amax, ev_dbg_set_attn_h16, ev_dbg_sk_taken, captured decodes of many shapes; 3: ev_set_arithmetic / ev_get_arithmetic, ev_profile_read_split, test hooks; everything of earlier versions unchanged */
 
 typedef struct ev_handle ev_handle;
 
@@ -203,6 +203,11 @@ int ev_dbg_conv_bench(ev_handle *h, int Cin, int Cout, int K, int dil, int B, in
  * of the input); on = 0: every tile pre-scans its input (the behaviour before ABI 4; also what inputs without bounds get).  The environment
  * variable EV_NO_AMAX=1 presets 0 for handles created afterwards.  Results differ only through the choice of the power-of-two block scale. */
 int ev_dbg_set_amax(ev_handle *h, int on);
+/* Diagnostic / A-B switch (ABI 4): on = 1 (default): under arithmetic setting 16 the self-attention of the U-Net's transformer blocks (transformer.py:262-271)
+ * runs on the fp16 matrix pipe — q, k, v leave the LayerNorm + projection kernel as fp16 piece pairs times a power of two that the loader derives from a
+ * bound no input can exceed, and both products of the attention use all piece products (22-bit operands, fp32 accumulation); on = 0: the attention
+ * stays on the fp32 MFMA as before ABI 4.  EV_NO_ATTN_H16=1 presets 0 for handles created afterwards.  Arithmetic settings 6 / 0 never take this path. */
+int ev_dbg_set_attn_h16(ev_handle *h, int on);
 
 /* Diagnostic: the control words of the balanced ("stream-K") launches (ev_kernels.h, SkCtl) after a device synchronisation:
  * out3 = {launches so far (epoch), arrivals of an unfinished launch (0), hand-off waits that ran out and were recomputed}. */

@@ -5,7 +5,9 @@
   * a ragged batch padded with `mel_mean` through the whole vocoder;
   * an Inf / a NaN in one utterance must not touch the utterance that shares its tile (ADVICE round 3);
   * 64-channel chunks of very different magnitude on the balanced build (the accumulators' unit changes by a factor of up to 2^80);
-  * weights that are not the exact sum of three bf16 pieces (1e-39, 1e-35): the checkpoint loads and the layer runs on the fp32 build.
+  * weights that are not the exact sum of three bf16 pieces (1e-39, 1e-35): the checkpoint loads and the layer runs on the fp32 build;
+  * the self-attention on the fp16 pipe (attn_out_h16_kernel): keys / values of very different magnitude, peaked and flat softmaxes, and the whole
+    decoder with that path on and off.
 """
 import importlib.util
 import os
@@ -182,3 +184,74 @@ def test_vocoder_with_and_without_amax_slots_agree():
     for y in (y_on, y_off):
         assert float((y[:3] - ref).pow(2).mean().sqrt()) <= 1e-4
     voc.engine.close()
+
+
+def _attn_ref64(qkv, lengths, w_out, b_out, hid):
+    B, T, _ = qkv.shape
+    q, k, v = (qkv[..., i * 128:(i + 1) * 128].double().view(B, T, 2, 64).transpose(1, 2) for i in range(3))
+    mask = (torch.arange(T)[None] < lengths[:, None]).double()
+    s = q @ k.transpose(-1, -2) / 8.0 + mask.repeat_interleave(2, dim=0).view(B, 2, 1, T)      # FLOAT mask, added (transformer.py:266-271)
+    att = (torch.softmax(s, dim=-1) @ v).transpose(1, 2).reshape(B, T, 128)
+    return hid.double() + att @ w_out.double().T + b_out.double()
+
+
+@pytest.mark.parametrize("case", ["plain", "quiet_keys", "quiet_values", "peaked", "large"])
+def test_attention_on_the_fp16_pipe_vs_fp64(eng, case):
+    """attn_out_h16_kernel against fp64, beside the fp32-MFMA kernel on the same data.  q / k / v are stored as two fp16 pieces times ONE power of
+    two per tensor, so what matters is data far below the tensor's maximum: half of the keys (values) 2^-12 below the others, softmaxes peaked
+    on one key (scores +-60), and magnitudes near the top of the scaled range.  Error is taken relative to the RMS of the attention term."""
+    g = torch.Generator().manual_seed(len(case))
+    B, T = 4, 132
+    qkv = torch.randn(B, T, 384, generator=g)
+    if case == "quiet_keys":
+        qkv[:, ::2, 128:256] *= 2.0 ** -12
+    elif case == "quiet_values":
+        qkv[:, ::2, 256:384] *= 2.0 ** -12
+    elif case == "peaked":
+        qkv[..., :256] *= 5.0
+    elif case == "large":
+        qkv *= 300.0
+        qkv[..., :128] *= 1e-3                                              # (scores stay moderate)
+    hid = torch.randn(B, T, 256, generator=g)
+    w_out = torch.randn(256, 128, generator=g) / 128 ** 0.5
+    b_out = torch.randn(256, generator=g) * 0.1
+    lengths = torch.tensor([132, 100, 1, 77])
+    ref = _attn_ref64(qkv, lengths, w_out, b_out, hid)
+    term = (ref - hid.double() - b_out.double())
+    valid = (torch.arange(T)[None] < lengths[:, None])
+    scale = float(term[valid].pow(2).mean().sqrt())
+    errs = {}
+    for on in (True, False):
+        eng.set_attn_h16(on)
+        got = eng.op_attn_out(qkv.cuda(), lengths.cuda(), w_out, b_out, hid.cuda()).cpu().double()
+        errs[on] = float((got - ref)[valid].abs().max()) / scale
+    eng.set_attn_h16(True)
+    # fp32-grade: within 2e-5 of the attention term's RMS — or, where scores of +-300 make the fp32 chain itself coarser than that ("large":
+    # fp32 rounding of a score near 300 is 3e-5, and it sits in an exponent), no worse than the fp32-MFMA kernel on the same data
+    assert errs[True] <= max(2e-5, 1.5 * errs[False]), (case, errs)
+    assert errs[True] <= 4 * errs[False] + 2e-6, (case, errs)              # the class of the fp32 chain, not merely inside the tolerance
+
+
+def test_decoder_with_attention_on_the_fp16_and_fp32_pipes_agree():
+    """The whole CFM decode (batch 64 x 258 frames: the full-resolution transformer blocks have the 256 row tiles of 64 that put LayerNorm + QKV
+    on ln_qkv_h16_kernel, hence the attention on attn_out_h16_kernel, with a short last query tile of 2) against the same decode with the
+    fp32-MFMA attention: they differ by rounding only — far inside the 1e-4 mel tolerance — and the fp16 path is deterministic."""
+    from emojivoice_amd import weights as W
+    from emojivoice_amd.matcha_tts import MatchaTTS
+
+    model = MatchaTTS(W.synthetic_matcha_state(), device="cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, T = 64, 258
+    mu = torch.randn(B, 80, T, generator=g).cuda()
+    lengths = torch.tensor([258, 200, 17, 258] * 16).cuda()
+    spk = torch.randn(B, model.spk_emb_dim, generator=g).cuda()
+    z = torch.randn(B, 80, T, generator=g).cuda()
+    outs = {True: [], False: []}
+    for on in (True, False, True):
+        model.engine.set_attn_h16(on)
+        outs[on].append(model.decode(mu, lengths, 2, spk=spk, z=z)[1].cpu())
+    model.engine.set_attn_h16(True)
+    assert torch.equal(outs[True][0], outs[True][1])
+    diff = float((outs[True][0] - outs[False][0]).abs().max())
+    assert 0.0 < diff <= 2e-5, diff                                        # (0 would mean the switch did nothing)
+    model.engine.close()
