@@ -1377,6 +1377,19 @@ int launch_attn(ev_handle* h, const float* QKV, int ld, float* O, int ldo, const
     return 0;
 }
 
+// attn_out_h16_kernel adds the frame mask to the scores as one more MFMA: in accumulator units the mask is m 8 sq sk, an exact power of two that
+// must split into two fp16 NUMBERS mask_a mask_b (normal range 2^-14 .. 2^15).  False: it does not (scales far outside anything a checkpoint
+// produces) — the caller keeps the fp32 form.
+bool attn_mask_split(const float* qkv_scale, float* mask_a, float* mask_b) {
+    int eq = 0, ek = 0;
+    if (!(qkv_scale[0] > 0.f) || !(qkv_scale[1] > 0.f) || std::frexp(qkv_scale[0], &eq) != 0.5f || std::frexp(qkv_scale[1], &ek) != 0.5f) return false;
+    const int e = 3 + (eq - 1) + (ek - 1);              // log2(8 sq sk)
+    const int ea = std::min(15, std::max(-14, e / 2)), eb = e - ea;
+    if (eb < -14 || eb > 15) return false;
+    *mask_a = (float)std::ldexp(1.0, ea); *mask_b = (float)std::ldexp(1.0, eb);
+    return true;
+}
+
 // The powers of two by which ln_qkv_h16_kernel scales q, k, v before it splits them into fp16 pieces.  A LayerNorm output obeys
 // |y_c| <= sqrt(C - 1) |gamma_c| + |beta_c| whatever its input (the normalised deviation of one of C numbers is at most sqrt(C - 1)), so
 // |(W y)_j| <= sum_c |W_jc| (sqrt(C - 1) |gamma_c| + |beta_c|) =: bound_j.  scale = the power of two that maps max_j bound_j into (16384, 32768]:
@@ -1402,7 +1415,8 @@ void qkv_pack_scales(const HostTensor* g, const HostTensor* b, std::initializer_
         e = std::min(40, std::max(-40, e));
         tmp[t++] = (float)std::ldexp(1.0, e);
     }
-    if (t == 3) for (int i = 0; i < 3; ++i) out[i] = tmp[i];
+    float ma, mb;
+    if (t == 3 && attn_mask_split(tmp, &ma, &mb)) for (int i = 0; i < 3; ++i) out[i] = tmp[i];
 }
 
 // attention of both heads + output projection + residual in one launch (attn_out_kernel): H += Wout . attn(QKV) + bout, in place.
@@ -1418,7 +1432,10 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
     AttnOutParams p;
     memset(&p, 0, sizeof p);
     const bool h16 = qkv_scale != nullptr;
-    if (h16) { p.inv_sq = 1.0f / qkv_scale[0]; p.inv_sk = 1.0f / qkv_scale[1]; p.inv_sv = 1.0f / qkv_scale[2]; p.Wouth = Lo.Wh; p.wo_scale = Lo.wh_scale; }
+    if (h16) {
+        p.inv_sq = 1.0f / qkv_scale[0]; p.inv_sk = 1.0f / qkv_scale[1]; p.inv_sv = 1.0f / qkv_scale[2]; p.Wouth = Lo.Wh; p.wo_scale = Lo.wh_scale;
+        if (!attn_mask_split(qkv_scale, &p.mask_a, &p.mask_b) || !Lo.Wh) return fail(h, "launch_attn_out: q / k scales %g, %g outside the fp16 form's range", qkv_scale[0], qkv_scale[1]);
+    }
     const int B = g.nrows / g.S;
     p.QKV = QKV; p.ld = ld; p.rowmask = rowmask; p.Wout = Lo.W; p.S = g.S; p.P = g.P; p.T = g.T; p.B = B; p.nq = (g.T + 31) / 32; p.scale = 0.125f;
     p.xcd_map = (B % 8 == 0) ? 1 : 0;
@@ -3099,8 +3116,10 @@ int ev_op_attn_out(ev_handle* h, const float* d_qkv, const int32_t* d_lengths, i
         float mx[3] = {0.f, 0.f, 0.f};
         for (size_t i = 0; i < hq.size(); ++i) { const float a = std::fabs(hq[i]); if (std::isfinite(a)) { float& m = mx[(i % 384) / 128]; m = std::max(m, a); } }
         for (int i = 0; i < 3; ++i) sc[i] = mx[i] > 0.f ? (float)std::ldexp(1.0, std::min(40, std::max(-40, (int)std::floor(std::log2(32768.0 / mx[i]))))) : 1.f;
-        if (!rc && hipMalloc((void**)&packed, hq.size() * 4) != hipSuccess) rc = fail(h, "ev_op_attn_out: out of memory");
-        if (!rc) {
+        float ma, mb;
+        const bool fits = attn_mask_split(sc, &ma, &mb);                   // (else: the fp32 form, as the model would)
+        if (!rc && fits && hipMalloc((void**)&packed, hq.size() * 4) != hipSuccess) rc = fail(h, "ev_op_attn_out: out of memory");
+        if (!rc && fits) {
             const size_t npairs = hq.size() / 2;
             hipLaunchKernelGGL(qkv_pack_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, h->stream, d_qkv, packed, npairs, sc[0], sc[1], sc[2]);
         }

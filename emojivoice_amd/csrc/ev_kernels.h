@@ -5268,6 +5268,7 @@ struct AttnOutParams {
     unsigned long long* stamps; // diagnostic (EV_ATTN_STAMPS): six s_memrealtime stamps per workgroup, or null
     // attn_out_h16_kernel: QKV holds fp16 piece pairs times the powers of two sq / sk / sv (ln_qkv_h16_kernel, qkv_pack)
     float inv_sq, inv_sk, inv_sv;
+    float mask_a, mask_b;       // powers of two, both fp16 numbers, mask_a mask_b = 8 sq sk (the frame mask in accumulator units)
     const void* Wouth; float wo_scale;   // the projection as two fp16 pieces in conv_h16_kernel's fragment order, times wo_scale
 };
 // one packed word pair -> two fp32 values: words (hi c, hi c+1), (lo c, lo c+1)
@@ -5653,17 +5654,20 @@ __global__ __launch_bounds__(256, 2) void attn_out_kernel(const AttnOutParams p)
 //           (16 MFMAs per 32-key tile for 64 dims; the three-product form would need 12 plus a re-arrangement of K in the vector ALUs).
 //   P . V:  O^T[column][q] += sum_key V[key][column] P[q][key] over the 128 fp16 COLUMNS of V's row (both pieces of 64 dims: four M tiles); the A
 //           operand is the transposed read ds_read_b64_tr_b16 of the V tile as it lies (row stride 320 B: four keys' 64-byte blocks on disjoint
-//           banks), the B operands are hP and lP straight from the score registers — P' = 2^13 exp2(s - m) <= 8192 as two pieces — whose key
+//           banks), the B operands are hP and lP straight from the score registers — P' = 2^8 exp2(s - mref) <= 2^15 as two pieces — whose key
 //           order (register r of lane half lh = key (r & 3) + 8 (r >> 2) + 4 lh) the transposed reads follow.  O[dim] = the hi column's row + the
 //           lo column's row, both in one lane (registers 4a + e and 4a + 2 + e): added once after the key loop.
-// Neither tile passes through the vector ALUs: global -> registers -> LDS as bytes.  The frame mask is added with the scale in one FMA per score.
+// Neither tile passes through the vector ALUs: global -> registers -> LDS as bytes, row addresses in the loads' scalar offset.  The frame mask is
+// a 17th MFMA of the scores; the softmax reference follows the running maximum lazily (see the loop), so a tile costs ~130 vector instructions
+// beside its 33 MFMAs (the first version, with per-lane row arithmetic, an FMA-added mask and eager rescaling: ~230).  The launch time did not
+// move with that (82 us at T = 516): it is set by per-workgroup latencies and the third, nearly empty round of workgroups — profiles/r04_attn_h16_ablation.txt.
 // Arithmetic: all piece products of 22-bit operands, fp32 accumulation — the class of the convolutions' setting 16.
 // ---------------------------------------------------------------------------
 typedef short ev_v4s __attribute__((__vector_size__(4 * sizeof(short))));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define AOH_KRS 272
 #define AOH_VRS 320
-#define AOH_WB (32 * AOH_KRS + 32 * AOH_VRS + 256)     // a wave's K tile, V tile, 32 mask values (19200 bytes; four waves, two workgroups per CU: 150 KB)
+#define AOH_WB (32 * AOH_KRS + 32 * AOH_VRS + 256)     // a wave's K tile and V tile (19200 bytes; four waves, two workgroups per CU: 150 KB)
 __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -5690,28 +5694,39 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
     stamp(0);
     char* Kt = (char*)smem + wave * AOH_WB;            // [32 keys][AOH_KRS]: the key rows of head h as they lie in the packed tensor
     char* Vt = Kt + 32 * AOH_KRS;                      // [32 keys][AOH_VRS]
-    float* Mt = (float*)(Vt + 32 * AOH_VRS);           // [32] additive masks of the tile's keys, log2 domain
     const __amdgpu_buffer_rsrc_t rQ = ev_rsrc(p.QKV), rM = ev_rsrc(p.rowmask), rW = ev_rsrc(p.Wouth);
     const float L2E = 1.44269504088896340736f;
     const unsigned ldb = (unsigned)p.ld * 4u;
     const int nkt = (p.T + 31) / 32, nh0 = (nkt + 1) / 2;
     const int kt0 = kh ? nh0 : 0, kt1 = kh ? nkt : nh0;
-    // staging: float4 j of this lane = (key row 4j + lane/16, words 4 (lane % 16) ..): a load instruction covers 4 rows x 256 B
+    // staging: float4 j of this lane = (key row 4j + lane/16, words 4 (lane % 16) ..): a load instruction covers 4 rows x 256 B.  The row of a
+    // load is wave-uniform up to lane/16: it rides in the instruction's SCALAR offset, the lane's part is one register for the whole loop
+    // (as per-lane row arithmetic this cost ~50 vector instructions per tile, a quarter of the loop's).
     f32x4 kr[8], vr[8];
     float mk = 0.f;
     const int srow = lane >> 4, sc4 = (lane & 15) * 4;
     const unsigned kcol = (unsigned)(128 + h * 64 + sc4) * 4u, vcol = (unsigned)(256 + h * 64 + sc4) * 4u;
-    auto kv_issue = [&](int kt) {      // every load unconditional: keys beyond the utterance re-read its last frame and are masked out
+    const unsigned kvo = (unsigned)srow * ldb + kcol, vvo = (unsigned)srow * ldb + vcol;
+    auto kv_issue = [&](int kt) {
+        if (kt * 32 + 32 <= p.T) {                      // (wave-uniform)
+            const unsigned so = (rowbase + (unsigned)(kt * 32)) * ldb;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int tk = kt * 32 + 4 * j + srow;
-            const unsigned ro = (rowbase + (unsigned)(tk < p.T ? tk : p.T - 1)) * ldb;
-            kr[j] = ev_bload4(rQ, ro + kcol, 0);
-            vr[j] = ev_bload4(rQ, ro + vcol, 0);
+            for (int j = 0; j < 8; ++j) {
+                kr[j] = ev_bload4(rQ, kvo, so + (unsigned)(4 * j) * ldb);
+                vr[j] = ev_bload4(rQ, vvo, so + (unsigned)(4 * j) * ldb);
+            }
+            mk = ev_bload1(rM, (unsigned)li * 4u, (rowbase + (unsigned)(kt * 32)) * 4u);
+        } else {                                        // the utterance's last tile: keys beyond it re-read its last frame (and get no weight below)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int tk = kt * 32 + 4 * j + srow;
+                const unsigned ro = (rowbase + (unsigned)(tk < p.T ? tk : p.T - 1)) * ldb;
+                kr[j] = ev_bload4(rQ, ro + kcol, 0);
+                vr[j] = ev_bload4(rQ, ro + vcol, 0);
+            }
+            const int tm = kt * 32 + li;
+            mk = ev_bload1(rM, (rowbase + (unsigned)(tm < p.T ? tm : p.T - 1)) * 4u, 0);
         }
-        const int tm = kt * 32 + li;
-        const float m = ev_bload1(rM, (rowbase + (unsigned)(tm < p.T ? tm : p.T - 1)) * 4u, 0);
-        mk = tm < p.T ? m * L2E : -1e30f;
     };
     if (kt0 < kt1) kv_issue(kt0);
     // Q operands: lane (query li, half lh), step g = dims 8g + 4lh .. + 3 = words (h01, l01, h23, l23) of the packed row
@@ -5726,13 +5741,24 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
             qb1[g] = b1; qb2[g] = b2;
         }
     }
+    // The additive frame mask (1 inside the utterance's length, 0 on its padded frames: a FLOAT mask, transformer.py:266-271) joins the scores as
+    // one more MFMA: in accumulator units it is m 8 sq sk — an exact power of two, split by the host into mask_a mask_b, both fp16 numbers —
+    // in k slot 0 of lane half 0: A = m[key] mask_a, B = mask_b.
     const float q_unit = p.scale * L2E * p.inv_sq * p.inv_sk;       // accumulator units -> log2-domain scores
+    f32x4 mb4 = {0.f, 0.f, 0.f, 0.f};
+    {
+        const f16x2 mbp = {(_Float16)(lh == 0 ? p.mask_b : 0.f), (_Float16)0.f};
+        mb4[0] = __builtin_bit_cast(float, mbp);
+    }
     f32x16 o[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[m][r] = 0.f;
-    float mrun = -1e30f, lrun = 0.f;
+    // Online softmax with a LAZY reference: probabilities are taken against mref, which follows the running maximum only when that has grown by
+    // more than 2^7 (a wave-uniform, rare branch: after the first tile of most rows never) — P' = 2^8 exp2(s - mref) <= 2^15 stays an fp16 number,
+    // and the usual per-tile rescaling of O (64 registers) and of the row sums disappears from the loop.
+    float mref = -1e30f, lrun = 0.f;
     // transposed reads: lane 4q + pp of the 16-lane group g16 supplies (key 4 (g16 >> 1) + q [+ 16 step + 8 e4], columns 16 (g16 & 1) + 4 pp .. [+ 32 mt])
     const __attribute__((address_space(3))) char* vtr = (const __attribute__((address_space(3))) char*)(Vt + (4 * (lane >> 5) + ((lane >> 2) & 3)) * AOH_VRS +
                                                                                                        2 * (16 * ((lane >> 4) & 1) + 4 * (lane & 3)));
@@ -5745,46 +5771,53 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
             *(f32x4*)(Kt + (4 * j + srow) * AOH_KRS + sc4 * 4) = kr[j];
             *(f32x4*)(Vt + (4 * j + srow) * AOH_VRS + sc4 * 4) = vr[j];
         }
-        Mt[li] = mk;
+        f32x4 ma4 = {0.f, 0.f, 0.f, 0.f};
+        {
+            const f16x2 map = {(_Float16)(lh == 0 ? mk * p.mask_a : 0.f), (_Float16)0.f};
+            ma4[0] = __builtin_bit_cast(float, map);
+        }
         kv_issue(kt + 1 < kt1 ? kt + 1 : kt);          // next tile (after the last: a harmless re-read)
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ma4), __builtin_bit_cast(f16x8, mb4), s, 0, 0, 0);
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const f16x8 a = __builtin_bit_cast(f16x8, *(const f32x4*)(krow + 32 * g));
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, qb1[g]), s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, qb2[g]), s, 0, 0, 0);
         }
-        float mx = -1e30f;
+        float mx = fmaxf(s[0], s[1]);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const f32x4 m4 = *(const f32x4*)(Mt + 8 * a + 4 * lh);
+        for (int r = 2; r < 16; r += 2) mx = fmaxf(mx, fmaxf(s[r], s[r + 1]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * q_unit;
+        if (__any(mx > mref + 7.f)) {                  // (wave-uniform)
+            const float mnew = mx > mref + 7.f ? mx : mref;
+            const float alpha = __builtin_amdgcn_exp2f(mref - mnew);
+            lrun *= alpha;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s[4 * a + e] = fmaf(s[4 * a + e], q_unit, m4[e]); mx = fmaxf(mx, s[4 * a + e]); }
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
+            mref = mnew;
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mnew = fmaxf(mrun, mx);
-        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-        const float msub = mnew - 13.f;                 // P' = 2^13 P: the pieces of small probabilities keep their bits
+        const float nb = 8.f - mref;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], q_unit, nb));
+        if (kt * 32 + 32 > p.T) {                       // (wave-uniform: the last tile) keys beyond the utterance get no weight
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = (kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh < p.T) ? s[r] : 0.f;
+        }
         float ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - msub); ps += s[r]; }
-        ps += __shfl_xor(ps, 32, 64);
-        lrun = lrun * alpha + ps;
-        mrun = mnew;
+        for (int r = 0; r < 16; ++r) ps += s[r];
+        lrun += ps;                                     // (this lane half's keys; the halves are added behind the loop)
         f16x8 ph[2], pl[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const _Float16 hh = (_Float16)s[r];
             ph[r >> 3][r & 7] = hh;
             pl[r >> 3][r & 7] = (_Float16)(s[r] - (float)hh);
-        }
-        if (!__all(alpha == 1.0f)) {                   // (wave-uniform: the running maximum of most tiles after the first few is old)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[m][r] *= alpha;
         }
 #pragma unroll
         for (int st = 0; st < 2; ++st)
@@ -5798,6 +5831,8 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
                 o[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pl[st], o[m], 0, 0, 0);
             }
     }
+    lrun += __shfl_xor(lrun, 32, 64);
+    const float mrun = mref;
     stamp(2);
     // hi column row + lo column row: od[m][a] = dims 16 m + 4 a + 2 lh + (0, 1) of query li, un-normalised, in units of 2^13 sv
     float od[4][4][2];
@@ -5838,7 +5873,7 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
         const float m1 = Ps[8 * 256 + lane], l1 = Ps[8 * 256 + 64 + lane];
         const float mm = fmaxf(mrun, m1);
         const float a0 = __builtin_amdgcn_exp2f(mrun - mm), a1 = __builtin_amdgcn_exp2f(m1 - mm);
-        const float inv = 1.0f / (lrun * a0 + l1 * a1);           // (the 2^13 of P' cancels between O and l; sv stays: see above)
+        const float inv = 1.0f / (lrun * a0 + l1 * a1);           // (the 2^8 of P' cancels between O and l; sv stays: see above)
         const float w0 = a0 * inv, w1 = a1 * inv;
 #pragma unroll
         for (int m = 0; m < 4; ++m)
