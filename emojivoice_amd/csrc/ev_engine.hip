@@ -2159,21 +2159,23 @@ int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* in
         const HostTensor *tw = T_(p + ".mlp.1.weight"), *tb = T_(p + ".mlp.1.bias");
         if (!c1w || !c1b || !c2w || !c2b || !rw || !rb || !tw || !tb) return 1;
         // [block1 conv (k = 3) | res_conv (1x1 -> centre tap)] stacked along the output axis, input channels [c0, c1)
-        auto stack = [&](int c0, int c1, bool with_bias, ConvLayer& L) -> int {
-            const int Co = (int)c1w->shape[0], Ci = (int)c1w->shape[1], K = (int)c1w->shape[2], Cr = (int)rw->shape[0], n = c1 - c0;
+        // npad > c1 - c0: the layer is declared npad channels wide with ZERO weights on the channels past c1 - the fp16 builds take inputs in
+        // whole 64-channel chunks, and what lies behind the slice in the same row (rn[0]'s x share: the first channels of mu) then meets zeros
+        auto stack = [&](int c0, int c1, bool with_bias, ConvLayer& L, int npad = 0) -> int {
+            const int Co = (int)c1w->shape[0], Ci = (int)c1w->shape[1], K = (int)c1w->shape[2], Cr = (int)rw->shape[0], nr = c1 - c0, n = std::max(nr, npad);
             std::vector<float> wt((size_t)(Co + Cr) * n * K, 0.f), bt((size_t)(Co + Cr), 0.f);
             for (int co = 0; co < Co; ++co)
-                for (int ci = 0; ci < n; ++ci)
+                for (int ci = 0; ci < nr; ++ci)
                     for (int k = 0; k < K; ++k) wt[((size_t)co * n + ci) * K + k] = c1w->p[((size_t)co * Ci + c0 + ci) * K + k];
             for (int co = 0; co < Cr; ++co)
-                for (int ci = 0; ci < n; ++ci) wt[((size_t)(Co + co) * n + ci) * K + K / 2] = rw->p[(size_t)co * Ci + c0 + ci];
+                for (int ci = 0; ci < nr; ++ci) wt[((size_t)(Co + co) * n + ci) * K + K / 2] = rw->p[(size_t)co * Ci + c0 + ci];
             for (int co = 0; co < Co; ++co) bt[co] = c1b->p[co];
             for (int co = 0; co < Cr; ++co) bt[Co + co] = rb->p[co];
             HostTensor wh, bh;
             wh.p = wt.data(); wh.ndim = 3; wh.shape[0] = Co + Cr; wh.shape[1] = n; wh.shape[2] = K;
             bh.p = bt.data(); bh.ndim = 1; bh.shape[0] = Co + Cr;
             if (pack_conv(h, L, wh, with_bias ? &bh : nullptr, 1)) return 1;
-            L.macs_per_row = (double)Co * n * K + (double)Cr * n;          // the reference's arithmetic (zero taps are not work)
+            L.macs_per_row = (double)Co * nr * K + (double)Cr * nr;        // the reference's arithmetic (zero taps and zero channels are not work)
             return 0;
         };
         if ((int)rw->shape[1] != (int)c1w->shape[1] || (int)c1w->shape[2] != 3) return fail(h, "resnet %d: unexpected conv shapes", i);
@@ -2181,7 +2183,10 @@ int ev_load_estimator(ev_handle* h, const float* blob, const ev_tensor_index* in
         REQ(pack_conv(h, w.rn[i].c2, *c2w, c2b, 1));
         if (i == 0) {   // split along Cin at n_feats: [x | mu, spk]
             const int nf = h->dims.n_feats, cin = (int)c1w->shape[1];
-            REQ(stack(0, nf, false, w.rn0_c1r_x));
+            // x share: n_feats = 80 channels, read as two 64-channel chunks of the [x | mu | spk] row (EV_RN0_PAD=0: as 80 channels on the fp32 MFMA)
+            static const bool no_pad = getenv("EV_RN0_PAD") && atoi(getenv("EV_RN0_PAD")) == 0;
+            const int npad = (!no_pad && nf % 64 != 0 && ((nf + 63) & ~63) <= cin) ? ((nf + 63) & ~63) : 0;
+            REQ(stack(0, nf, false, w.rn0_c1r_x, npad));
             REQ(stack(nf, cin, true, w.rn0_c1r_ms));
         }
         REQ(upload_vec(h, m, p + ".block1.block.1.weight", &w.rn[i].g1));

@@ -5840,6 +5840,10 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int a = 0; a < 4; ++a) { od[m][a][0] = o[m][4 * a] + o[m][4 * a + 2]; od[m][a][1] = o[m][4 * a + 1] + o[m][4 * a + 3]; }
+    // Merge, projection and the epilogue's operand loads overlap: the lean epilogue requests its residual rows first and runs `after_issue` while
+    // they fly (the hook conv_gemm_sk_kernel sums its partial tiles in) — here the merge of the key halves and the projection, ~4 us.
+    f32x16 acc[2][1];
+    auto merge_project = [&]() {
     // ---- first weight fragments of the projection (two fp16 pieces, conv_h16_kernel's fragment order: row tile 2 wave + a, 16-deep step ks, piece pc
     // at (((2 wave + a) 8 + ks) 2 + pc) KiB), into the staging registers: they land while the key halves are merged.  Ring slot of (a, ks, pc) =
     // kr / vr [4 (ks & 1) + 2 a + pc] for even / odd ks >> 1 ... i.e. steps 0-3 now, steps 4-7 as their slots come free.
@@ -5894,7 +5898,6 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
     // ---- projection: Y^T[256][32] = Wout . O^T, K = 128 = 8 steps of 16, three piece products; accumulators in units of wo_scale sv,
     // bias preloaded (lean epilogue convention)
     const float u = p.wo_scale / p.inv_sv, inv_u = 1.0f / u;
-    f32x16 acc[2][1];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -5929,12 +5932,12 @@ __global__ __launch_bounds__(256, 2) void attn_out_h16_kernel(const AttnOutParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][0][r] *= inv_u;
     stamp(4);
+    };
     // ---- + residual rows, store (rows of THIS utterance only: a tile's tail rows may belong to the next one)
-    conv_epilogue_lean<2, 1, 1>(p.ep, acc, smem + wave * (32 * 68), wave * 64, (int)rowbase + q0, lane, (int)rowbase, (int)rowbase + p.T);
+    conv_epilogue_lean<2, 1, 1>(p.ep, acc, smem + wave * (32 * 68), wave * 64, (int)rowbase + q0, lane, (int)rowbase, (int)rowbase + p.T, merge_project);
     stamp(5);
 }
 
-// ---------------------------------------------------------------------------
 // attention_part_kernel + attention_merge_kernel: the small-launch build of attention_kernel.  A batch-1 decode has 6-10
 // workgroups per attention launch, and each of their waves is a serial chain over all 9-17 key tiles: 64 MFMAs = 1.7 us of its
 // SIMD's matrix pipe per tile, i.e. the launch is bound by the pipes of the handful of CUs it runs on (27-48 us, 60 launches

@@ -253,5 +253,5 @@ def test_decoder_with_attention_on_the_fp16_and_fp32_pipes_agree():
     model.engine.set_attn_h16(True)
     assert torch.equal(outs[True][0], outs[True][1])
     diff = float((outs[True][0] - outs[False][0]).abs().max())
-    assert 0.0 < diff <= 2e-5, diff                                        # (0 would mean the switch did nothing)
+    assert 0.0 < diff <= 5e-5, diff                                        # (0 would mean the switch did nothing)
     model.engine.close()
