@@ -627,8 +627,9 @@ def main():
             ach_split = sp_fl / (sp_ms * 1e-3) / 1e12
             roofline = {"bound": "mfma", "achieved": round(ach_split, 2), "peak": round(peak_split, 1), "unit": "TFLOP/s", "frac": round(ach_split / peak_split, 4),
                         "traffic": traffic,
-                        "kernel": ("conv_h16_kernel + conv_h16_bal_kernel + resblock_pair_h16_kernel + ln_mlp_h16_kernel + ln_qkv_h16_kernel (fp32 contractions as 3 fp16 products of two "
-                                   "block-scaled fp16 pieces per operand on v_mfma_f32_32x32x16_f16, fp32 accumulation)") if ARITH == 16 else
+                        "kernel": ("conv_h16_kernel + conv_h16_bal_kernel + resblock_pair_h16_kernel + ln_mlp_h16_kernel + ln_qkv_h16_kernel + attn_out_h16_kernel (fp32 contractions as 3 fp16 "
+                                   "products of two block-scaled fp16 pieces per operand on v_mfma_f32_32x32x16_f16 / 16x16x32_f16, fp32 accumulation; the attention's QK^T and PV "
+                                   "execute all 4 piece products and are still priced at 3)") if ARITH == 16 else
                                   ("conv_split_kernel + conv_split_bal_kernel + resblock_pair_split_kernel + ln_mlp_split_kernel (fp32 contractions as "
                                    f"{SPLIT_PRODUCTS} bf16 products per element pair on v_mfma_f32_32x32x16_bf16, fp32 accumulation)"),
                         "peak_note": f"2500 TFLOP/s dense 16-bit MFMA / {SPLIT_PRODUCTS} products per fp32 multiply-add; `achieved` counts ALGORITHMIC fp32 FLOP"
@@ -641,7 +642,7 @@ def main():
                         "ms_per_step": round(sp_ms, 2),
                         "fp32_mfma_family": {"achieved": round(f32_fl / (f32_ms * 1e-3) / 1e12, 2) if f32_n else None, "peak": PEAK_FP32_MFMA_TFLOPS,
                                              "frac": round(f32_fl / (f32_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if f32_n else None,
-                                             "kernel": "attn_out_kernel + conv_gemm_kernel (attention; layers whose channel counts the split builds do not take)",
+                                             "kernel": "conv_gemm_kernel (+ attn_out_kernel where the fp16 attention does not apply): layers whose channel counts the split builds do not take",
                                              "launches_per_step": int(f32_n), "ms_per_step": round(f32_ms, 2)}}
         else:
             roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

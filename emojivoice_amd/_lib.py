@@ -23,7 +23,7 @@ EXPORTS = [
     "ev_text_encoder_status", "ev_stft_magnitude", "ev_denoise", "ev_align", "ev_dbg_conv_bench",
     "ev_workspace_bytes", "ev_cfm_decode", "ev_estimator", "ev_hifigan", "ev_profile_enable", "ev_profile_read", "ev_profile_read_split", "ev_dbg_last_cfg", "ev_set_arithmetic", "ev_get_arithmetic",
     "ev_op_conv1d", "ev_op_groupnorm_mish", "ev_op_layernorm", "ev_op_split_pieces", "ev_op_attention", "ev_op_ln_mlp", "ev_set_mrf_streams_max",
-    "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out", "ev_dbg_set_amax", "ev_dbg_set_attn_h16", "ev_dbg_sk_taken",
+    "ev_cfm_decode2", "ev_reserve", "ev_alloc_count", "ev_dbg_sk_stats", "ev_op_attn_out", "ev_dbg_set_amax", "ev_dbg_set_attn_h16", "ev_dbg_set_chain", "ev_dbg_sk_taken",
 ]
 
 
@@ -103,6 +103,7 @@ def load_library() -> C.CDLL:
     lib.ev_get_arithmetic.argtypes = [vp]
     lib.ev_dbg_set_amax.argtypes = [vp, i32]
     lib.ev_dbg_set_attn_h16.argtypes = [vp, i32]
+    lib.ev_dbg_set_chain.argtypes = [vp, i32]
     lib.ev_dbg_sk_taken.argtypes = [vp]
     lib.ev_dbg_sk_taken.restype = C.c_int64
     lib.ev_op_conv1d.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp, vp]
@@ -358,6 +359,10 @@ class Engine:
     def set_attn_h16(self, on: bool) -> None:
         """True (default): under arithmetic setting 16 the U-Net's self-attention runs on the fp16 pipe (attn_out_h16_kernel); False: on the fp32 MFMA."""
         self._check(self.lib.ev_dbg_set_attn_h16(self.h, int(bool(on))), "ev_dbg_set_attn_h16")
+
+    def set_chain(self, on: bool) -> None:
+        """True (default): ResBlock1 chains that qualify (narrow levels, k = 3) run as one launch (resblock_chain_h16_kernel); False: as three fused pairs."""
+        self._check(self.lib.ev_dbg_set_chain(self.h, int(bool(on))), "ev_dbg_set_chain")
 
     def arithmetic(self) -> int:
         return int(self.lib.ev_get_arithmetic(self.h))

@@ -136,6 +136,7 @@ struct ev_handle {
     int fuse128 = 3;            // fuse C=128 pairs up to this kernel size (EV_FUSE128=0/3/7/11)
     bool fuse_attn = true;      // EV_FUSE_ATTN=0: attention and its output projection as separate launches (attention_kernel + a 1x1 conv)
     bool attn_h16 = true;       // EV_NO_ATTN_H16=1: the fused attention stays on the fp32 MFMA under arithmetic setting 16 too
+    bool use_chain = true;      // ev_dbg_set_chain(h, 0) / EV_NO_CHAIN=1: ResBlock1 chains as three fused pairs instead of one launch
     bool fuse_mlp = true;       // EV_FUSE_MLP=0: LayerNorm / QKV / feed-forward of the transformer blocks as separate launches
     int gn_stats_tiles = 0;         // set by every launch_conv: row tiles whose GroupNorm statistics the launch left in Epi::gn_part (0 = none)
     int fuse_mlp_min_tiles = 96;    // EV_FUSE_MLP_MIN=<32-row tiles>: below this the separate (split-K) launches are used (measured with
@@ -1112,6 +1113,76 @@ int launch_pair(ev_handle* h, const ConvLayer& L1, const ConvLayer& L2, const fl
     return 0;
 }
 
+// A whole ResBlock1 — three (dilated conv, conv) pairs with their residual adds — in one launch (resblock_chain_h16_kernel): the narrow levels under
+// arithmetic setting 16, kernel sizes whose summed halos leave most of a tile to store.  chain_ok() is the gate; the caller falls back to three
+// launch_pair calls.  EV_NO_CHAIN=1 switches it off (A/B).
+inline int chain_halo(const ConvLayer* L1, const ConvLayer* L2) { int hs = 0; for (int m = 0; m < 3; ++m) hs += L1[m].halo_lo + L2[m].halo_lo; return hs; }
+inline bool chain_ok(const ev_handle* h, const ConvLayer* L1, const ConvLayer* L2, int C) {
+    static const bool off = getenv("EV_NO_CHAIN") != nullptr;
+    static const int max_halo = getenv("EV_CHAIN_MAXHALO") ? atoi(getenv("EV_CHAIN_MAXHALO")) : 12;
+    if (off || !h->use_chain || h->split_terms != 16 || (C != 32 && C != 64)) return false;
+    int hb = 0;
+    for (int m = 0; m < 3; ++m) {
+        const ConvLayer &a = L1[m], &b = L2[m];
+        if (!a.Wh || !b.Wh || !a.bias || !b.bias || a.sparse_taps || b.sparse_taps || a.Kpad != C || b.Kpad != C || a.Mpad != b.Mpad || a.Mpad != L1[0].Mpad ||
+            a.halo_lo != a.halo_hi || b.halo_lo != b.halo_hi || a.ntaps != L1[0].ntaps || b.ntaps != L2[0].ntaps || a.ntaps > 64 || b.ntaps > 64) return false;
+        hb = std::max(hb, std::max(a.halo_lo, b.halo_lo));
+    }
+    const int NT = C == 32 ? 256 : 128, hs = chain_halo(L1, L2);
+    return hs <= max_halo && 2 * hb <= EV_HALO && NT - 2 * hs >= NT / 2;
+}
+int launch_chain(ev_handle* h, const ConvLayer* L1, const ConvLayer* L2, const float* X, float* Y, int C, const Geom& g, const Epi& e) {
+    ChainParams cp;
+    memset(&cp, 0, sizeof cp);
+    ConvParams& p = cp.c2;
+    p.X = X; p.ldx = C; p.Cin = C; p.isplit_log2 = 31;
+    p.Mpad = L2[2].Mpad; p.Kpad = L2[2].Kpad;
+    p.Y = Y; p.ldy = C; p.Cout = C; p.osplit_log2 = 31; p.mmul = 1;
+    p.nrows = g.nrows; p.S = g.S; p.P = g.P; p.T = g.T;
+    p.pro_lrelu = 1; p.pro_slope = 0.1f;
+    p.scale = 1.f; p.R = nullptr; p.ldr = C; p.accum = e.accum; p.div3 = e.div3; p.act2_lrelu = e.act2_lrelu; p.act2_slope = e.act2_slope;
+    p.rmax = nullptr; p.yold = e.yold; p.ymax_mul = 1; h->amax_emitted = false;
+    if (e.ymax && (!e.accum || e.yold) && h->use_amax) { p.ymax = e.ymax; h->amax_emitted = true; }
+    if ((double)g.nrows * C * 4.0 >= 4294967296.0) return fail(h, "tensor exceeds the 4 GiB buffer-addressing limit: split the batch");
+    int hb = 0;
+    double macs = 0;
+    for (int m = 0; m < 3; ++m) {
+        cp.W1h[m] = L1[m].Wh; cp.W2h[m] = L2[m].Wh; cp.w1_scale[m] = L1[m].wh_scale; cp.w2_scale[m] = L2[m].wh_scale;
+        cp.b1[m] = L1[m].bias; cp.b2[m] = L2[m].bias; cp.tl1[m] = L1[m].taplist[0]; cp.tl2[m] = L2[m].taplist[0];
+        hb = std::max(hb, std::max(L1[m].halo_lo, L2[m].halo_lo));
+        macs += L1[m].macs_per_row + L2[m].macs_per_row;
+    }
+    cp.ntaps1 = L1[0].ntaps; cp.ntaps2 = L2[0].ntaps; cp.hb = hb; cp.halo = chain_halo(L1, L2); cp.mid_slope = 0.1f;
+    const int NT = C == 32 ? 256 : 128, RSB = 4 * C + 16;
+    cp.out_rows = NT - 2 * cp.halo; p.mtiles = 1; p.ntiles = (g.nrows + cp.out_rows - 1) / cp.out_rows;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (h->prof) {
+        if (h->ev_used + 2 > h->ev_pool.size()) {
+            for (int i = 0; i < 64; ++i) { hipEvent_t ev; HIPCHK(h, hipEventCreate(&ev)); h->ev_pool.push_back(ev); }
+        }
+        e0 = h->ev_pool[h->ev_used++]; e1 = h->ev_pool[h->ev_used++];
+        HIPCHK(h, hipEventRecord(e0, h->stream));
+    }
+    const int lean = (e.accum || e.div3 || e.act2_lrelu) ? 3 : 1;
+    const size_t smem = std::max((size_t)(NT + EV_HALO) * RSB + 64, (size_t)4 * 32 * 36 * sizeof(float));
+    const dim3 grid(p.ntiles);
+#define EV_CHAIN(WM, WN) do { \
+        if (lean == 1) { ensure_dyn_smem<resblock_chain_h16_kernel<WM, WN, 1>>(smem, h->device); hipLaunchKernelGGL((resblock_chain_h16_kernel<WM, WN, 1>), grid, dim3(256), smem, h->stream, cp); } \
+        else { ensure_dyn_smem<resblock_chain_h16_kernel<WM, WN, 3>>(smem, h->device); hipLaunchKernelGGL((resblock_chain_h16_kernel<WM, WN, 3>), grid, dim3(256), smem, h->stream, cp); } } while (0)
+    if (C == 32) EV_CHAIN(1, 4); else EV_CHAIN(2, 2);
+#undef EV_CHAIN
+    HIPCHK(h, hipGetLastError());
+    h->last_cfg = 180 + L2[0].ntaps;
+    if (h->prof) {
+        HIPCHK(h, hipEventRecord(e1, h->stream));
+        const double valid_rows = (double)(g.nrows / g.S) * g.T;
+        h->prof_flops += 2.0 * macs * valid_rows;
+        h->prof_launches += 1;
+        h->prof_recs.push_back({1, C, C, L1[0].ntaps, g.nrows, 180 + L2[0].ntaps, lean, 2.0 * macs * valid_rows});
+    }
+    return 0;
+}
+
 int launch_gn(ev_handle* h, const float* X, int ldx, float* Y, int ldy, const float* gamma, const float* beta, const float* rowmask,
               const float* temb, const float* R, int ldr, const Geom& g, int C, int mode, const float* part = nullptr) {
     GNParams p;
@@ -1510,7 +1581,7 @@ int launch_attn_out(ev_handle* h, const float* QKV, int ld, const ConvLayer& Lo,
         const double fl = (double)B * ((double)H * 4.0 * g.T * (double)g.T * 64.0 + 2.0 * Lo.macs_per_row * g.T);
         h->prof_flops += fl;
         h->prof_launches += 1;
-        h->prof_recs.push_back({4, 128, 256, 1, g.nrows, 30, 1, fl});
+        h->prof_recs.push_back({4, 128, 256, 1, g.nrows, h16 ? 31 : 30, 1, fl});      // (31: attn_out_h16_kernel, counted with the fp16 builds)
     }
     return 0;
 }
@@ -2720,6 +2791,19 @@ int ev_hifigan(ev_handle* h, const float* d_mel, int B, int T, float* d_wav, voi
             h->stream = own ? h->mrf_stream[j - 1] : s0;
             float* pp[2] = {own ? v.Pax[j - 1][l] : v.Pa[l], own ? v.Pbx[j - 1][l] : v.Pb[l]};
             float* t1 = own ? v.T1x[j - 1][l] : v.T1[l];
+            if (h->fuse_pairs && chain_ok(h, w.c1[i * 3 + j], w.c2[i * 3 + j], C)) {
+                // the whole ResBlock in one launch: x never leaves the CU between its three pairs (resblock_chain_h16_kernel)
+                if (ms && j > 0) HIPCHK(h, hipStreamWaitEvent(h->stream, h->mrf_ev[j - 1], 0));
+                Epi e2;
+                float* y = v.XS[l];
+                e2.accum = (j > 0);
+                if (j == 2) { e2.div3 = 1; e2.act2_lrelu = 1; e2.act2_slope = (i == 3) ? 0.01f : 0.1f; }
+                if (l < 4) with_slots(e2, x, nullptr, y, 1);
+                if (launch_chain(h, w.c1[i * 3 + j], w.c2[i * 3 + j], x, y, C, v.g[l], e2)) return 1;
+                wrote(y, e2.accum != 0);
+                if (ms) HIPCHK(h, hipEventRecord(h->mrf_ev[j], h->stream));
+                continue;
+            }
             for (int mm = 0; mm < 3; ++mm) {
                 if (ms && mm == 2 && j > 0) HIPCHK(h, hipStreamWaitEvent(h->stream, h->mrf_ev[j - 1], 0));   // the sum so far is in XS
                 Epi e2; e2.R = x; e2.ldr = C;                                          // c2 + x
@@ -2807,7 +2891,7 @@ int ev_profile_read(ev_handle* h, double* conv_ms, double* conv_flops, int64_t* 
             if (FILE* f = fopen(dump, "a")) {
                 fprintf(f, "# kind Cin Cout ntaps nrows cfg lean launches total_ms TFLOP/s\n");
                 for (auto& a : aggs)
-                    fprintf(f, "%s %4d %4d %3d %9d %3d %d %5d %9.3f %7.1f\n", a.r.kind == 0 ? "conv" : (a.r.kind == 1 ? "pair" : (a.r.kind == 2 ? "lnff" : "lnqkv")), a.r.Cin, a.r.Cout, a.r.ntaps, a.r.nrows, a.r.cfg, a.r.lean,
+                    fprintf(f, "%s %4d %4d %3d %9d %3d %d %5d %9.3f %7.1f\n", a.r.kind == 0 ? "conv" : (a.r.kind == 1 ? "pair" : (a.r.kind == 2 ? "lnff" : (a.r.kind == 3 ? "lnqkv" : "attn "))), a.r.Cin, a.r.Cout, a.r.ntaps, a.r.nrows, a.r.cfg, a.r.lean,
                             a.n, a.ms, a.fl / (a.ms * 1e9));
                 fclose(f);
             }
@@ -2840,6 +2924,14 @@ int ev_dbg_set_amax(ev_handle* h, int on) {
     return 0;
 }
 
+// Diagnostic / A-B switch (ABI v4): 1 (default) = ev_hifigan runs the ResBlock1 chains that qualify (narrow levels, k = 3) as ONE launch each
+// (resblock_chain_h16_kernel), 0 = as three fused pairs
+int ev_dbg_set_chain(ev_handle* h, int on) {
+    if (!h) return 1;
+    h->use_chain = on != 0;
+    return 0;
+}
+
 // Diagnostic / A-B switch (ABI v4): 1 (default) = under arithmetic setting 16 the fused attention runs on the fp16 pipe (attn_out_h16_kernel, q / k / v
 // left as fp16 piece pairs by ln_qkv_h16_kernel), 0 = it stays on the fp32 MFMA (attn_out_kernel).  EV_NO_ATTN_H16=1 presets 0.
 int ev_dbg_set_attn_h16(ev_handle* h, int on) {
@@ -2858,7 +2950,7 @@ int ev_profile_read_split(ev_handle* h, double* ms_out, double* flops_out, int64
     if (h->prof_recs.size() * 2 == h->ev_used)
         for (size_t i = 0; i < h->prof_recs.size(); ++i) {
             const auto& r = h->prof_recs[i];
-            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 46 || r.cfg == 47 || r.cfg == 66 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && (r.cfg == 120 || r.cfg == 121)) || (r.kind == 3 && r.cfg == 122);
+            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 46 || r.cfg == 47 || r.cfg == 66 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && (r.cfg == 120 || r.cfg == 121)) || (r.kind == 3 && r.cfg == 122) || (r.kind == 4 && r.cfg == 31);
             if (!split) continue;
             float t = 0;
             HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));

@@ -3362,6 +3362,227 @@ __global__ __launch_bounds__(256, 2) void resblock_pair_h16_kernel(const PairPar
 }
 
 // ---------------------------------------------------------------------------
+// resblock_chain_h16_kernel: a WHOLE ResBlock1 (hifigan/models.py:90-97: three times x = x + c2(lrelu(c1_d(lrelu(x)))), dilations 1, 3, 5) in one
+// launch, for the narrow levels (C = 32 / 64) and the kernel size whose halos allow it (k = 3: 12 rows a side).  The pairs of such a chain are
+// half HBM-bound: each reads its 1.1 GB input and writes 1.1 GB back (levels 3 / 4 at batch 64) for 2 x 3 taps of arithmetic.  Here the running x
+// never leaves the CU: it lives in the accumulator layout in registers (fp32, 32 per lane), its leaky-relu goes to LDS as two fp16 planes
+// for c1, the intermediate likewise for c2 (the hand-over of resblock_pair_h16_kernel, twice per pair), and c2's result is added to the registers.
+// One tile of NT frames is read once and its middle NT - 2 halo frames are stored once: a third of the pairs' traffic, a third of their
+// staging / epilogue episodes, for halo / NT more arithmetic (rows within `halo` of the tile's edges see zeros where their neighbours' frames
+// would be and are not stored).  Scales as in the pair kernel: one power of two per staged tile from the workgroup's maximum, found in registers.
+// ---------------------------------------------------------------------------
+struct ChainParams {
+    ConvParams c2;                 // geometry + epilogue view: X = the ResBlock's input, Y = its output (or the running mean it joins), flags; R unused
+    const void* W1h[3]; const void* W2h[3]; float w1_scale[3], w2_scale[3];
+    const float* b1[3]; const float* b2[3];
+    const int2* tl1[3]; const int2* tl2[3];
+    int ntaps1, ntaps2;            // taps of the dilated convs / of the plain ones
+    int hb;                        // LDS rows in front of the tile (>= every conv's halo): zero, like the rows behind it
+    int halo;                      // sum over the pairs of (c1's halo + c2's halo): frames a side that are computed but not stored
+    int out_rows;                  // NT - 2 halo
+    float mid_slope;
+};
+template <int WAVES_M, int WAVES_N, int LEAN>
+__global__ __launch_bounds__(256, 2) void resblock_chain_h16_kernel(const ChainParams cp) {
+    constexpr int TM = 1, TN = 2;
+    constexpr int C = 32 * WAVES_M;
+    constexpr int NT = WAVES_N * TN * 32;
+    constexpr int RSB = 4 * C + 16;                     // LDS row stride in bytes: two fp16 planes of all C channels + 16
+    constexpr int NS = C / 16, H = NS / 2;
+    static_assert(WAVES_M * WAVES_N == 4 && (C == 32 || C == 64), "4 waves per workgroup; C = 32 / 64");
+    const ConvParams& p = cp.c2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* Xb = (char*)smem;                             // [hb | NT | hb][RSB]
+    float* red = smem + ((NT + EV_HALO) * RSB) / 4;     // 16 floats behind the tile: the waves' maxima (two alternating sets + their finite-only repeats)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int li = lane & 31, lh = lane >> 5;
+    const int nt = ev_xcd_remap(blockIdx.x, p.ntiles);
+    const int n0 = nt * cp.out_rows;
+    const int g0 = n0 - cp.halo;
+    {   // tiles whose output window holds no storable row do nothing
+        const int s0 = n0 % p.S, t_first = s0 - p.P;
+        int dist;
+        if (t_first >= 0 && t_first < p.T) dist = 0;
+        else if (t_first < 0) dist = -t_first;
+        else dist = p.S - s0 + p.P;
+        if (dist >= cp.out_rows || n0 + dist >= p.nrows) return;
+    }
+    const int HB = cp.hb;
+    const int KG16 = p.Kpad >> 4;
+    const unsigned wlane = (unsigned)lane * 16u;
+    const unsigned wbase = (unsigned)(wm * KG16) * 2048u;
+    EvAmax am = ev_amax_begin(p, g0 + wn * (TN * 32), TN * 32);
+    const __amdgpu_buffer_rsrc_t rX = ev_rsrc(p.X);
+    // ---- the running x of this wave's 32 channels x 64 frames, accumulator layout (lane = frame, registers = channels 8 q + 4 lh + e)
+    f32x16 xr[TN];
+    float inside[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = g0 + wn * (TN * 32) + j * 32 + li;
+        const bool in = n >= 0 && n < p.nrows;
+        const int t = in ? (n % p.S) - p.P : -1;
+        inside[j] = (t >= 0 && t < p.T) ? 1.f : 0.f;
+        const unsigned ro = (in ? (unsigned)n * (unsigned)p.ldx : 0u) * 4u + (unsigned)(wm * 32 + 4 * lh) * 4u;     // (row 0 is a zero pad row)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = ev_bload4(rX, ro + (unsigned)(8 * q) * 4u, 0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) xr[j][4 * q + e] = v[e];
+        }
+    }
+    // the rows in front of and behind the tile: zero for the whole chain (nothing writes them)
+    for (int i = tid; i < 2 * HB * (RSB / 16); i += 256) {
+        const int br = i / (RSB / 16), c16 = i % (RSB / 16);
+        const int row = br < HB ? br : NT + br;
+        uint4 z = {0u, 0u, 0u, 0u};
+        *(uint4*)(Xb + row * RSB + c16 * 16) = z;
+    }
+    f32x16 acc[TM][TN];
+    f32x4 A0[2][TM], A1[2][TM], A2[2][TM], A3[2][TM], B0[2][TN], B1[2][TN];
+    auto ldAp = [&](const __amdgpu_buffer_rsrc_t& rW, f32x4 (&dst)[2][TM], unsigned aoff) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) dst[pc][0] = ev_bload4(rW, wlane, aoff + (unsigned)(pc * 1024));
+    };
+    auto ldB = [&](f32x4 (&dst)[2][TN], const char* brow, int slab) {
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) dst[pc][j] = *(const f32x4*)(brow + j * 32 * RSB + pc * (2 * C) + slab * 32);
+    };
+    auto g_off = [&](int2 tlv, int g, int ngroups) -> unsigned {
+        const int gg = g < ngroups ? g : 0;             // (beyond the phase: a harmless re-read)
+        return (unsigned)__builtin_amdgcn_readlane(tlv.x, gg / H) + wbase + (unsigned)(2 * (gg % H)) * 2048u;
+    };
+    auto g_row = [&](int2 tlv, int g, int ngroups) -> int {
+        const int gg = g < ngroups ? g : 0;
+        return __builtin_amdgcn_readlane(tlv.y, gg / H);
+    };
+    auto acc_init = [&](const float* binit, float unit) {   // bias in accumulator units
+        f32x4 bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *(const f32x4*)(binit + wm * 32 + 8 * g + 4 * lh) * unit;
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][b][r] = bq[r >> 2][r & 3];
+    };
+    auto ring_fill = [&](const __amdgpu_buffer_rsrc_t& rW, int2 tlv, int ngroups) {
+        const unsigned o0 = g_off(tlv, 0, ngroups), o1 = g_off(tlv, 1, ngroups);
+        ldAp(rW, A0, o0); ldAp(rW, A1, o0 + 2048u); ldAp(rW, A2, o1); ldAp(rW, A3, o1 + 2048u);
+    };
+    auto kloop = [&](const __amdgpu_buffer_rsrc_t& rW, int2 tlv, int ngroups, const char* bbase) {
+        auto group = [&](f32x4 (&Aa)[2][TM], f32x4 (&Ab)[2][TM], int g) {
+            const char* brow = bbase + g_row(tlv, g, ngroups) * RSB;
+            const char* nbrow = bbase + g_row(tlv, g + 1, ngroups) * RSB;
+            const int s0 = 2 * (g % H), ns0 = 2 * ((g + 1) % H);
+            const unsigned nap = g_off(tlv, g + 2, ngroups);
+            ldB(B1, brow, s0 + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            evh_mma<TM, TN>(acc, Aa, B0);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(rW, Aa, nap);
+            ldB(B0, nbrow, ns0);
+            __builtin_amdgcn_sched_barrier(0);
+            evh_mma<TM, TN>(acc, Ab, B1);
+            __builtin_amdgcn_sched_barrier(0);
+            ldAp(rW, Ab, nap + 2048u);
+        };
+        ldB(B0, bbase + g_row(tlv, 0, ngroups) * RSB, 0);
+        int g = 0;
+        for (; g + 1 < ngroups; g += 2) { group(A0, A1, g); group(A2, A3, g + 1); }
+        if (g < ngroups) group(A0, A1, g);
+    };
+    auto wg_max = [&](float mx, int slot) -> float {        // workgroup maximum through LDS (one barrier)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        if (lane == 0) red[slot + wave] = mx;
+        ev_lds_barrier();
+        return fmaxf(fmaxf(red[slot], red[slot + 1]), fmaxf(red[slot + 2], red[slot + 3]));
+    };
+    // this lane's values (true units, any prologue applied) -> maximum over the workgroup -> scale -> two fp16 planes at rows r + HB.
+    // The barrier inside wg_max is also what lets the planes be overwritten: every wave has left the K loop that read them.
+    auto hand_over = [&](f32x16 (&v)[TN], int slot) -> float {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) mx = fmaxf(mx, fmaxf(fabsf(v[j][r]), fabsf(v[j][r + 1])));
+        float tmx = wg_max(mx, slot);
+        if (!evh_is_finite(tmx)) {                      // an Inf in the tile (workgroup-uniform slow path): the finite maximum sets the scale
+            mx = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float a = fabsf(v[j][r]); mx = fmaxf(mx, evh_is_finite(a) ? a : 0.f); }
+            tmx = wg_max(mx, 8 + slot);
+        }
+        const float sc = evh_scale_for(tmx);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn * (TN * 32) + j * 32 + li;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 w = {v[j][4 * g] * sc, v[j][4 * g + 1] * sc, v[j][4 * g + 2] * sc, v[j][4 * g + 3] * sc};
+                uint2 q0v, q1v;
+                evh_split4(w, q0v, q1v);
+                char* dst = Xb + (r + HB) * RSB + (wm * 32 + 8 * g + 4 * lh) * 2;
+                *(uint2*)(dst) = q0v; *(uint2*)(dst + 2 * C) = q1v;
+            }
+        }
+        return sc;
+    };
+    const char* bbase = Xb + (wn * (TN * 32) + li + HB) * RSB + 16 * lh;
+    const int ng1 = cp.ntaps1 * H, ng2 = cp.ntaps2 * H;
+#pragma unroll 1
+    for (int m = 0; m < 3; ++m) {
+        const __amdgpu_buffer_rsrc_t rW1 = ev_rsrc(cp.W1h[m]), rW2 = ev_rsrc(cp.W2h[m]);
+        const int2 tlv1 = (lane < cp.ntaps1) ? cp.tl1[m][lane] : make_int2(0, 0);
+        const int2 tlv2 = (lane < cp.ntaps2) ? cp.tl2[m][lane] : make_int2(0, 0);
+        ring_fill(rW1, tlv1, ng1);                          // c1's first fragments fly under the hand-over
+        // ---- lrelu(x) -> planes; c1
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][j][r] = ev_lrelu(xr[j][r], p.pro_slope);
+        const float sx = hand_over(acc[0], 0);
+        const float u1 = cp.w1_scale[m] * sx;
+        acc_init(cp.b1[m], u1);
+        ev_lds_barrier();
+        kloop(rW1, tlv1, ng1, bbase);
+        ring_fill(rW2, tlv2, ng2);
+        // ---- y1 = lrelu(c1 + b1), zero outside the utterance -> planes; c2
+        {
+            const float inv1 = 1.0f / u1;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const float f = inv1 * inside[j];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][j][r] = ev_lrelu(acc[0][j][r] * f, cp.mid_slope);
+            }
+        }
+        const float sy = hand_over(acc[0], 4);
+        const float u2 = cp.w2_scale[m] * sy;
+        acc_init(cp.b2[m], u2);
+        ev_lds_barrier();
+        kloop(rW2, tlv2, ng2, bbase);
+        // ---- x += c2 + b2 (zero outside the utterance: the next conv must see the padding the stored tensor would have)
+        {
+            const float inv2 = 1.0f / u2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xr[j][r] = fmaf(acc[0][j][r], inv2, xr[j][r]) * inside[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[0][j] = xr[j];
+    ev_amax_from_acc<TM, TN>(p, am, acc, g0 + wn * (TN * 32), lane);
+    conv_epilogue_lean<TM, TN, LEAN>(p, acc, smem + wave * (32 * (TM * 32 + 4)), wm * 32, g0 + wn * (TN * 32), lane, n0, n0 + cp.out_rows);
+    ev_amax_emit(p, am, g0 + wn * (TN * 32), TN * 32, lane);
+}
+
+// ---------------------------------------------------------------------------
 // resblock_pair_h16q_kernel: resblock_pair_h16_kernel with both K loops on v_mfma_f32_16x16x32_f16 (see conv_h16_kernel<..., Q = 1>: the 16 x 16
 // shape holds a higher clock under the chip's power limit).  A "group" of the K loops — two 16-deep slabs of one tap — is exactly one 32-deep
 // step here; a wave's 32 channels x 64 frames are 2 x 4 tiles of 16 x 16.  Weights: W1q / c2.Wq (16 x 16 x 32 fragment order), same pieces,

@@ -27,13 +27,13 @@
  *     handle's streams + hipFree + hipMalloc).  ev_reserve sizes everything once, up front, so that no later call at or below
  *     the reserved shape allocates or waits (a streaming server reserves its longest utterance: ev_alloc_count stays put).
  *   - Graph capture: ev_cfm_decode is capturable at any (B, Tp) the workspace already holds (ev_reserve, or an earlier eager call at the
- *     largest shape: planning must not allocate under capture): it enqueues kernels, one memset and one pinned-memory copy and never
- *     waits on the host.  A handle may hold captured calls of MANY shapes (ABI 4; a serving loop keeps one graph per utterance length)
+ *     largest shape: planning must not allocate under capture): it enqueues kernels only and never waits on the host.  A handle may hold captured calls of MANY shapes (ABI 4; a serving loop keeps one graph per utterance length)
  *     and serve eager calls of any shape in between: once a call has been captured, every call on the handle — captured or eager —
  *     begins by re-zeroing the estimator's part of the workspace for its own plan, so none depends on what another left there.  A
- *     captured call contains kernels and one memset only: the time-MLP output for its step count must already be on the device, i.e.
+ *     captured call consists of kernel nodes only (its re-zeroing is a kernel too): the time-MLP output for its step count must already be on the device, i.e.
  *     one EAGER ev_cfm_decode with the same n_steps must have run on the handle before (the handle keeps that output per step count;
- *     a host-to-device copy captured from pinned memory is not safe to replay on this runtime: later eager copies recycle its staging).
+ *     a host-to-device copy captured from pinned memory, and a captured memset, are not safe to replay on this runtime: later eager copies /
+ *     memsets recycle their staging — profiles/r04_graph_capture_h2d_hazard.txt).
  *     What returns an error instead of pulling memory from under the graphs: a growth of the workspace beyond what is reserved, more
  *     Euler steps than the workspace is planned for (64, or the largest n_steps of an earlier call), a captured call with a step
  *     count no eager call has used.
@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define EV_ABI_VERSION 4   /* 4: ev_dbg_set_amax, ev_dbg_set_attn_h16, ev_dbg_sk_taken, captured decodes of many shapes; 3: ev_set_arithmetic / ev_get_arithmetic, ev_profile_read_split, test hooks; everything of earlier versions unchanged */
+#define EV_ABI_VERSION 4   /* 4: ev_dbg_set_amax, ev_dbg_set_attn_h16, ev_dbg_set_chain, ev_dbg_sk_taken, captured decodes of many shapes; 3: ev_set_arithmetic / ev_get_arithmetic, ev_profile_read_split, test hooks; everything of earlier versions unchanged */
 
 typedef struct ev_handle ev_handle;
 
@@ -208,6 +208,11 @@ int ev_dbg_set_amax(ev_handle *h, int on);
  * bound no input can exceed, and both products of the attention use all piece products (22-bit operands, fp32 accumulation); on = 0: the attention
  * stays on the fp32 MFMA as before ABI 4.  EV_NO_ATTN_H16=1 presets 0 for handles created afterwards.  Arithmetic settings 6 / 0 never take this path. */
 int ev_dbg_set_attn_h16(ev_handle *h, int on);
+/* Diagnostic / A-B switch (ABI 4): on = 1 (default): under arithmetic setting 16, ev_hifigan runs a whole ResBlock1 (hifigan/models.py:90-97: three
+ * (dilated conv, conv) pairs with their residual adds) as ONE launch where the level is narrow (32 / 64 channels) and the kernel size small enough
+ * for the summed halos (k = 3): the running x stays in registers between the pairs; on = 0: three fused-pair launches as before.  EV_NO_CHAIN=1
+ * presets 0.  Results differ by rounding only (other tile boundaries, hence other power-of-two tile scales). */
+int ev_dbg_set_chain(ev_handle *h, int on);
 
 /* Diagnostic: the control words of the balanced ("stream-K") launches (ev_kernels.h, SkCtl) after a device synchronisation:
  * out3 = {launches so far (epoch), arrivals of an unfinished launch (0), hand-off waits that ran out and were recomputed}. */

@@ -27,6 +27,7 @@ CONFIG2_LAUNCH_LIST = [
     r"resblock_pair_h16q_kernel<2, 2, 3>", r"resblock_pair_h16q_kernel<1, 4, 3>",
     r"resblock_pair_h16_kernel<2, 2, 1>", r"resblock_pair_h16_kernel<1, 4, 1>", r"resblock_pair_h16_kernel<4, 1, 1>",
     r"resblock_pair_h16_kernel<2, 2, 3>", r"resblock_pair_h16_kernel<1, 4, 3>",
+    r"resblock_chain_h16_kernel<1, 4, 1>", r"resblock_chain_h16_kernel<2, 2, 1>", r"resblock_chain_h16_kernel<1, 4, 3>", r"resblock_chain_h16_kernel<2, 2, 3>",
     r"attn_out_kernel", r"attn_out_h16_kernel", r"groupnorm_mish_kernel<512, false>",
     r"conv_gemm_kernel<64, 64, 2, 2, false, false, 1, 1>", r"conv_gemm_kernel<64, 64, 2, 2, false, false, 0, 1>",
     r"conv_gemm_kernel<64, 128, 2, 2, false, false, 1, 1>", r"conv_gemm_kernel<64, 64, 2, 2, true, true, 0, 1>",

@@ -6,6 +6,7 @@
   * an Inf / a NaN in one utterance must not touch the utterance that shares its tile (ADVICE round 3);
   * 64-channel chunks of very different magnitude on the balanced build (the accumulators' unit changes by a factor of up to 2^80);
   * weights that are not the exact sum of three bf16 pieces (1e-39, 1e-35): the checkpoint loads and the layer runs on the fp32 build;
+  * a whole ResBlock1 in one launch (resblock_chain_h16_kernel) against the three fused pairs it replaces;
   * the self-attention on the fp16 pipe (attn_out_h16_kernel): keys / values of very different magnitude, peaked and flat softmaxes, and the whole
     decoder with that path on and off.
 """
@@ -255,3 +256,38 @@ def test_decoder_with_attention_on_the_fp16_and_fp32_pipes_agree():
     diff = float((outs[True][0] - outs[False][0]).abs().max())
     assert 0.0 < diff <= 5e-5, diff                                        # (0 would mean the switch did nothing)
     model.engine.close()
+
+
+@pytest.mark.parametrize("B,T", [(16, 516), (1, 132), (3, 40)])
+def test_vocoder_with_and_without_resblock_chains_agree(B, T):
+    """ev_hifigan with the k = 3 ResBlocks of the 64- and 32-channel levels as ONE launch each (the running x stays in registers between the three
+    (dilated conv, conv) pairs; tiles of 128 / 256 frames of which 12 a side are computed but not stored) against the same call with three fused
+    pairs per ResBlock, and both against the oracle.  Batch 1 and a 40-frame batch take the small-launch schedule (three streams); utterance
+    starts and ends fall inside tiles (T * 64 and T * 256 frames are no multiples of the stored windows of 104 / 232)."""
+    from emojivoice_amd import weights as W
+    from emojivoice_amd.hifigan import AttrDict, Generator, v1
+    from oracle import matcha_oracle as O
+
+    voc_sd = W.synthetic_hifigan_state()
+    voc = Generator(AttrDict(v1)).to("cuda:0")
+    voc.load_state_dict(voc_sd)
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    mel = torch.randn(B, 80, T, generator=g) * 2.0 - 5.0
+    mel[B - 1, :, : T // 2] = -11.5        # near-silence beside speech inside one tile: with uniform data every tile of either form takes the same
+                                           # power-of-two scale and the two forms agree bit for bit — the switch would show no effect
+    voc._sync_engine()
+    outs = {}
+    for on in (True, False, True):
+        voc.engine.set_chain(on)
+        y = voc(mel.cuda()).cpu()
+        if on and True in outs:
+            assert torch.equal(outs[True], y)                               # deterministic
+        outs[on] = y
+    voc.engine.set_chain(True)
+    rms = float((outs[True] - outs[False]).pow(2).mean().sqrt())
+    assert 0.0 < rms <= 1e-5, rms                                           # (0 would mean the switch did nothing)
+    nref = min(B, 2)
+    ref = O.hifigan_forward(voc_sd, mel[:nref], W.HIFIGAN_V1)
+    for y in outs.values():
+        assert float((y[:nref] - ref).pow(2).mean().sqrt()) <= 1e-4
+    voc.engine.close()
