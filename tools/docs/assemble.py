@@ -21,7 +21,8 @@ vals = {
     "CFM": f"{d['stage_ms']['cfm_decode']:.1f}", "VOC": f"{d['stage_ms']['hifigan']:.1f}", "CONVMS": f"{r['conv_ms_per_step']:.1f}",
     "FAMTF": f"{r['family_tflops']:.0f}", "CFMTF": f"{r['tflops_cfm_convs']:.0f}", "VOCTF": f"{r['tflops_hifigan_convs']:.0f}",
     "ACH": f"{r['achieved']:.0f}", "FRAC": f"{r['frac']:.2f}", "F32TF": f"{r['fp32_mfma_family']['achieved']:.0f}", "F32FRAC": f"{r['fp32_mfma_family']['frac']:.2f}",
-    "HBMGB": f"{tr.get('GB_per_step', 0):.0f}", "MELLINF": f"{cpu.get('parity_mel_linf', 0):.1e}", "WAVRMS": f"{cpu.get('parity_wav_rms', 0):.1e}",
+    "HBMGB": f"{tr.get('GB_per_step', 0):.0f}", "NFAM": str(r.get("family_launches_per_step", "")), "NSPLIT": str(r.get("launches_per_step", "")),
+    "NF32": str((r.get("fp32_mfma_family") or {}).get("launches_per_step", "")), "MELLINF": f"{cpu.get('parity_mel_linf', 0):.1e}", "WAVRMS": f"{cpu.get('parity_wav_rms', 0):.1e}",
     "FP32VALUE": f"{f32.get('value', 0):.0f}", "FP32MS": f"{f32.get('ms_per_step', 0):.1f}", "FP32MEL": f"{f32.get('mel_linf_vs_headline_arithmetic', 0):.1e}",
     "FP32WAV": f"{f32.get('wav_rms_vs_headline_arithmetic', 0):.1e}", "CPUVALUE": f"{cpu.get('value', 0):.1f}",
     "C5WARM": f"{(c5.get('warm') or {}).get('p50_ms', 0)}", "C5COLD": f"{(c5.get('cold_length') or {}).get('p50_ms', 0)}",
@@ -37,6 +38,11 @@ if c4:
     vals["CONFIG4"] = "CFM decode ms at n = " + ", ".join(f"{e['ode_steps']}: {e['cfm_ms']}" for e in c4["sweep"]) + \
         "; mel MSE vs n = 50: " + ", ".join(f"{e['mel_mse_vs_50']:.1e}" for e in c4["sweep"]) + \
         "; mel L∞ vs the CPU oracle at the same n ≤ " + f"{max(e['mel_linf_vs_cpu_same_n'] for e in c4['sweep']):.1e}"
+try:    # the PMC traffic file of this round, when the bench line quoted an older one
+    tj = json.load(open(os.path.join(repo, "profiles", "r04_conv_hbm_traffic_pmc.json")))
+    vals["HBMGB"] = f"{tj['hbm_GB_per_step']:.0f}"
+except Exception:
+    pass
 for kv in sys.argv[2:]:
     k, v = kv.split("=", 1)
     vals[k] = v

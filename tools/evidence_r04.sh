@@ -4,7 +4,7 @@ set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/ev4; rm -rf $O; mkdir -p $O
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 4 --warmup 2 --no-extras --no-cpu-baseline > $O/bench_b64.log 2>&1 &&
-python tools/trace_steps.py $O/stats 420 7 > $O/conv_per_pass.txt 2>&1
+python tools/trace_steps.py $O/stats 416 7 > $O/conv_per_pass.txt 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d $O/busy -- python3 bench.py --plain --no-pipeline --steps 1 --warmup 1 > $O/busy.log 2>&1 &&
 python tools/pmc_summary.py $O/busy > $O/mfma_busy_pmc.txt 2>&1
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/fetch -- python3 bench.py --plain --no-pipeline --steps 1 --warmup 1 > $O/fetch.log 2>&1 &&
