@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Differential fuzz of the 16-bit-pipe builds against the fp32 MFMA builds on ONE handle (ev_set_arithmetic 16 / 6 vs 0):
 random layer shapes on deep and shallow grids, odd lengths, prologue leaky-relu on / off, inputs scaled by 10^U(-5, 5) with a few
-outliers, and LayerNorm + QKV / LayerNorm + feed-forward rows.  Prints the worst error relative to the output scale per build.
+outliers, LayerNorm + QKV / LayerNorm + feed-forward rows, the fused attention on the fp16 pipe against the fp32-MFMA attention (ragged lengths, q / k / v of
+random magnitude), and the whole vocoder with its k = 3 ResBlocks as one launch against three fused pairs.  Prints the worst error relative to the
+output scale per build.
     python tools/fuzz_h16.py [n_cases] [seed]"""
 import os, sys
 import numpy as np
@@ -33,7 +35,7 @@ def note(cfg, arith, y, y0, what):
 bad = 0
 for case in range(n_cases):
     g = torch.Generator().manual_seed(int(rng.integers(1 << 30)))
-    kind = case % 4
+    kind = case % 6
     mag = 10.0 ** float(rng.uniform(-5, 5))
     if kind < 3:
         cin = int(rng.choice([64, 128, 192, 256, 512])); cout = int(rng.choice([64, 128, 192, 256, 384, 512]))
@@ -62,6 +64,37 @@ for case in range(n_cases):
             elif not torch.equal(y, y0):
                 print(f"FAIL arith {arith}: fp32 build {cfg} differs from itself  {what}", flush=True); bad += 1
         del xc
+    elif kind == 4:
+        # attn_out_h16_kernel (cfg 31) against attn_out_kernel on the same fp32 q | k | v: scores of moderate size, values of any size
+        B = int(rng.choice([1, 2, 3, 8, 17, 64])); T = int(rng.choice([32, 33, 67, 100, 132, 258, 260, 516])) if B < 17 else int(rng.choice([36, 98, 132]))
+        qkv = torch.randn(B, T, 384, generator=g)
+        sq = 10.0 ** float(rng.uniform(-2, 2))
+        qkv[..., :128] *= sq * float(rng.uniform(0.5, 3.0)); qkv[..., 128:256] /= sq; qkv[..., 256:] *= mag
+        if case % 3 == 0:
+            qkv[:, ::3, 128:] *= 2.0 ** -10                 # keys / values far below their neighbours
+        hid = torch.randn(B, T, 256, generator=g) * mag
+        w_out = torch.randn(256, 128, generator=g) / 128 ** 0.5; b_out = torch.randn(256, generator=g) * 0.1 * mag
+        lengths = torch.randint(1, T + 1, (B,), generator=g); lengths[0] = T
+        eng.set_arithmetic(16)
+        eng.set_attn_h16(False)
+        y0 = eng.op_attn_out(qkv.cuda(), lengths.cuda(), w_out, b_out, hid.cuda()).cpu()
+        eng.set_attn_h16(True)
+        y = eng.op_attn_out(qkv.cuda(), lengths.cuda(), w_out, b_out, hid.cuda()).cpu()
+        valid = (torch.arange(T)[None] < lengths[:, None])
+        bad += note(31, 16, (y - hid)[valid], (y0 - hid)[valid], f"attention B{B} T{T} |q| x{sq:.1e} |v| x{mag:.1e}")
+    elif kind == 5:
+        # the vocoder with resblock_chain_h16_kernel (cfg 183) against the same call with three fused pairs per ResBlock
+        if "voc" not in globals():
+            from emojivoice_amd import weights as W
+            from emojivoice_amd.hifigan import AttrDict, Generator, v1
+            voc = Generator(AttrDict(v1)).to("cuda:0"); voc.load_state_dict(W.synthetic_hifigan_state()); voc._sync_engine()
+        B = int(rng.choice([1, 2, 5])); T = int(rng.integers(8, 300))
+        mel = torch.randn(B, 80, T, generator=g) * float(rng.uniform(0.5, 3.0)) - float(rng.uniform(2, 8))
+        if case % 2:
+            mel[B - 1, :, : T // 2] = -11.5
+        voc.engine.set_chain(False); y0 = voc(mel.cuda()).cpu()
+        voc.engine.set_chain(True); y = voc(mel.cuda()).cpu()
+        bad += note(183, 16, y, y0, f"vocoder chains B{B} T{T}")
     else:
         rows = int(rng.choice([16384, 16640, 20011, 33280, 40000])) + int(rng.integers(0, 64))
         x = (torch.randn(rows, 256, generator=g) * float(rng.uniform(0.2, 3.0)) + float(rng.uniform(-1, 1))) * mag
