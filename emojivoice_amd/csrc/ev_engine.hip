@@ -41,6 +41,7 @@ struct ConvLayer {
     int2* taplist[3] = {nullptr, nullptr, nullptr};   // for BM = 128, 64, 32: [mtiles][EV_MAX_TAPS] {tap, row offset} (one shared row when dense)
     int* nact[3] = {nullptr, nullptr, nullptr};       // per-tile active tap count (null when dense)
     unsigned char nact64[16] = {0};                   // host copy of the BM = 64 counts of the first 16 M tiles (unit weights of the balanced build)
+    bool pair256_uniform = false;                     // Mpad % 256 == 0 and the two 128-channel tiles of every 256-channel tile carry the same tap list (conv_h16_bal_kernel<256, 128>)
     bool sparse_taps = false;
     bool tile128_exact = true;              // every 128-channel M tile carries exactly the taps of both its 64-channel halves (no union waste)
     int kstack_mt = 0, kstack_tap = 0;      // sparse_taps of the stacked [k-tap conv | 1x1 conv] kind: 32-channel tiles >= kstack_mt carry only tap kstack_tap
@@ -332,6 +333,12 @@ int finish_layer(ev_handle* h, ConvLayer& L, const std::vector<float>& Wh, const
                 if (nz) lists[k][t].push_back(make_int2(tap * plane_bytes, L.off[tap]));
                 else if (t * BM < L.Cout) L.sparse_taps = true;
             }
+    }
+    L.pair256_uniform = L.Mpad % 256 == 0;
+    for (int t = 0; t + 1 < L.Mpad / 128 && L.pair256_uniform; t += 2) {
+        const auto &a = lists[0][t], &b = lists[0][t + 1];
+        L.pair256_uniform = a.size() == b.size() && !a.empty();
+        for (size_t i = 0; i < a.size() && L.pair256_uniform; ++i) L.pair256_uniform = a[i].x == b[i].x && a[i].y == b[i].y;
     }
     L.tile128_exact = true;
     for (int t = 0; t < L.Mpad / 128 && t * 128 < L.Cout; ++t)
@@ -675,12 +682,17 @@ int launch_h16_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
     p.sk.ctrl = h->sk_ctrl; p.sk.flags = h->sk_ctrl + 16; p.sk.part = h->sk_part; p.sk.part_floats = EV_SK_PART_FLOATS;
     p.sk.q = (int)(U / G); p.sk.r = (int)(U % G); p.sk.spin_limit = h->sk_spin;
     if (h->sk_steal) { p.sk.claims = h->sk_ctrl + 16 + EV_SK_MAXWG; p.sk.seq = ++h->sk_seq; }
+    constexpr int NW = WM * WN;                         // 4 waves: two workgroups per CU; 8 waves (256 x 128 tiles): one
     const size_t xs = (size_t)(BN + ((lo.halo + 7) & ~7)) * EVH_RSB;
-    constexpr size_t es = (size_t)4 * 32 * (BM / WM + 4) * sizeof(float);
+    constexpr size_t es = (size_t)NW * 32 * (BM / WM + 4) * sizeof(float);
     size_t smem = xs > es ? xs : es;
     p.sk.lds_word = (int)smem;
-    smem += 64;                                         // the wait word + three sets of the waves' maxima
-    static_assert((size_t)BM * BN <= EV_SK_PART_FLOATS, "hand-off slot");
+    smem += 16 + 3 * NW * sizeof(float) + 16;           // the wait word + three sets of the waves' maxima
+    static_assert((size_t)BM * BN <= 2 * EV_SK_PART_FLOATS, "hand-off slot");
+    if ((size_t)BM * BN > EV_SK_PART_FLOATS) {          // 256 x 128 tiles: slots twice as large, half as many workgroups (the area is sized for 1024 x 2 x 64 KB)
+        if ((size_t)G * 2 > EV_SK_MAXWG) return fail(h, "launch_h16_bal: %d workgroups of 256 x 128 tiles exceed the hand-off area", G);
+        p.sk.part_floats = (int)((size_t)BM * BN);
+    }
     static const char* stamp_file = getenv("EV_BAL_STAMPS");         // diagnostic: phase stamps of a few workgroups, once per layer shape
     static std::vector<long> stamped;
     const long sig = ((long)p.nrows << 24) ^ ((long)p.Kpad << 12) ^ p.Mpad ^ ((long)p.ntaps << 40);
@@ -695,6 +707,16 @@ int launch_h16_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
         static const int stag = getenv("EV_BAL_STAGGER") ? atoi(getenv("EV_BAL_STAGGER")) : 0;
         p.stagger_slots = (wpc == 2) ? stag : 0;
     }
+    if constexpr (NW == 8) {                            // passes of 32 rows: 5 cover a 3-tap layer's tile, 6 the widest halo
+        const bool narrow8 = BN + p.halo_lo + p.halo_hi <= 32 * 5;
+        if (lean_acc(p)) {
+            if (narrow8) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 3, 5>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 3, 5>), dim3(G), dim3(512), smem, h->stream, p); }
+            else { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 3, 6>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 3, 6>), dim3(G), dim3(512), smem, h->stream, p); }
+        } else {
+            if (narrow8) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 1, 5>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 1, 5>), dim3(G), dim3(512), smem, h->stream, p); }
+            else { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 1, 6>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 1, 6>), dim3(G), dim3(512), smem, h->stream, p); }
+        }
+    } else {
     const bool narrow = BN + p.halo_lo + p.halo_hi <= 16 * 9;         // a 3-tap layer: nine staging passes instead of twelve
     if (lean_acc(p)) {
         if (narrow) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 3, 9>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 3, 9>), dim3(G), dim3(256), smem, h->stream, p); }
@@ -702,6 +724,7 @@ int launch_h16_bal(ev_handle* h, ConvParams p, const LaunchOpts& lo, int wpc) {
     } else {
         if (narrow) { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 1, 9>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 1, 9>), dim3(G), dim3(256), smem, h->stream, p); }
         else { ensure_dyn_smem<conv_h16_bal_kernel<BM, BN, WM, WN, 1>>(smem, lo.device); hipLaunchKernelGGL((conv_h16_bal_kernel<BM, BN, WM, WN, 1>), dim3(G), dim3(256), smem, h->stream, p); }
+    }
     }
     if (d) {
         HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -901,6 +924,19 @@ int launch_conv(ev_handle* h, const ConvLayer& L, const float* X, int ldx, float
     if (cfg == 60) {   // 128 x 128 on the bf16 pipe, balanced persistent grid
         p.mtiles = L.Mpad / 128; p.ntiles = (g.nrows + 127) / 128; p.taplist = L.taplist[0]; p.nact_tab = L.nact[0]; p.tl_stride = L.sparse_taps ? EV_MAX_TAPS : 0;
         static const int bal_wgs = getenv("EV_SPLIT_BAL_WGS") ? atoi(getenv("EV_SPLIT_BAL_WGS")) : 2;    // A/B: persistent workgroups per CU (1 or 2)
+        // EV_BAL_WIDE=1 (A/B, measured null — not the default): layers of 256-channel multiples as ONE eight-wave workgroup per CU on 256 x 128
+        // tiles, so that the X tile is staged once for both halves of the output channels instead of by two lockstep workgroups.  Same box, batch 64:
+        // 256 -> 256 k3 2.585 -> 2.766 ms (T), 2.254 -> 2.426 ms (T / 2), 512 -> 512 1.447 -> 1.415 ms; decode 25.9 -> 26.5 ms (gpurun_out/s22).
+        // Halving the bytes of the burst a chunk begins with does not shorten the chunk: what the two workgroups of a CU wait for in lockstep
+        // is latency, and eight waves meet at every barrier instead of four.
+        static const bool use_wide = getenv("EV_BAL_WIDE") && atoi(getenv("EV_BAL_WIDE")) != 0;
+        bool wide = use_wide && h->split_terms == 16 && L.Wh && L.Mpad % 256 == 0 && L.Cout == L.Mpad && bal_wgs != 1;
+        wide = wide && L.pair256_uniform;
+        if (wide) {
+            p.mtiles = L.Mpad / 256; p.mt_mul = 2;
+            if (launch_h16_bal<256, 128, 4, 2>(h, p, lo, 1)) return 1;
+            cfg = 68;
+        } else
         if (h->split_terms == 16 && L.Wh) { if (launch_h16_bal<128, 128, 2, 2>(h, p, lo, bal_wgs == 1 ? 1 : 2)) return 1; cfg = 66; }
         else if (launch_split_bal<128, 128, 2, 2>(h, p, lo, bal_wgs == 1 ? 1 : 2)) return 1;
     } else
@@ -2950,7 +2986,7 @@ int ev_profile_read_split(ev_handle* h, double* ms_out, double* flops_out, int64
     if (h->prof_recs.size() * 2 == h->ev_used)
         for (size_t i = 0; i < h->prof_recs.size(); ++i) {
             const auto& r = h->prof_recs[i];
-            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 46 || r.cfg == 47 || r.cfg == 66 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && (r.cfg == 120 || r.cfg == 121)) || (r.kind == 3 && r.cfg == 122) || (r.kind == 4 && r.cfg == 31);
+            const bool split = (r.kind == 0 && (r.cfg == 40 || r.cfg == 41 || r.cfg == 46 || r.cfg == 47 || r.cfg == 66 || r.cfg == 68 || r.cfg == 43 || r.cfg == 49 || r.cfg == 60)) || (r.kind == 1 && r.cfg >= 140) || (r.kind == 2 && (r.cfg == 120 || r.cfg == 121)) || (r.kind == 3 && r.cfg == 122) || (r.kind == 4 && r.cfg == 31);
             if (!split) continue;
             float t = 0;
             HIPCHK(h, hipEventElapsedTime(&t, h->ev_pool[2 * i], h->ev_pool[2 * i + 1]));

@@ -91,6 +91,7 @@ struct ConvParams {
                                             // a bound read from slots the same launch is updating would depend on timing — and the tile scales, hence the bits, with it)
     const unsigned* xmax; int xmax_n;       // consumer: slots of X and their count (null: pre-scan)
     int stagger_slots;                      // workgroups co-resident per CU (0 = no start stagger), see conv_gemm_kernel
+    int mt_mul;                             // conv_h16_bal_kernel with 256-channel M tiles: tap list / tap count of M tile mt are those of the 128-channel tile mt_mul * mt (0 = 1)
     unsigned long long* stamps;             // dbg bit 16: per-workgroup {start, first stage done, K loop done, end} s_memtime stamps
     int dbg;                                // ablation bits for tools/conv_bench.py: 1 skip X loads, 2 skip A loads, 4 skip epilogue
     SkCtl sk;                               // conv_gemm_kernel<..., SK = true>: the balanced persistent grid (units = (tile, 32-channel k-chunk))
@@ -2028,11 +2029,15 @@ __global__ __launch_bounds__(256, 2) void conv_split_bal_kernel(const ConvParams
 // ---------------------------------------------------------------------------
 // XP = staging passes of 16 rows a chunk is read in: 12 covers the widest halo, 9 the 3-tap layers of the U-Net (host-checked: BN + halo <= 16 XP) —
 // twelve registers fewer held beside the accumulators and the weight ring.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN, int XP = (BN + EV_HALO) / 16, int XK = (XP > 9 ? 8 : XP)>
-__global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p) {
+// EIGHT waves (<256, 128, 4, 2, ...>: one workgroup per CU, all 256 output channels of a 128-frame tile; passes of 32 rows): the two workgroups of
+// a CU in the four-wave build run the same program in lockstep and stage the SAME X rows when the layer has two M tiles — merged, the tile is
+// staged once (half the bytes of the burst every chunk begins with), the MFMA phase is the same two waves per SIMD.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int LEAN, int XP = (BN + EV_HALO) / (4 * WAVES_M * WAVES_N), int XK = (XP > 9 ? 8 : XP)>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, WAVES_M * WAVES_N == 4 ? 2 : 1) void conv_h16_bal_kernel(const ConvParams p) {
     constexpr int TM = BM / WAVES_M / 32;
     constexpr int TN = BN / WAVES_N / 32;
-    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1 && LEAN != 0, "balanced build: 4 waves, lean epilogue");
+    constexpr int NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
+    static_assert((NW == 4 || NW == 8) && TM >= 1 && TN >= 1 && LEAN != 0, "balanced build: 4 waves (two workgroups per CU) or 8 (one), lean epilogue");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* Xb = (char*)smem;
     const int tid = threadIdx.x;
@@ -2059,9 +2064,8 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
     bool pend_pub = false;
     const unsigned wlane = (unsigned)lane * 16u;
     const int KG16 = p.Kpad >> 4;
-    constexpr int TPR = EVX_KC / 4, RPS = 256 / TPR;
+    constexpr int TPR = EVX_KC / 4, RPS = NTHR / TPR;   // staging: 16 threads per row, 16 (32) rows per pass
     const int srow = tid / TPR, sc4 = (tid % TPR) * 4;
-    static_assert(RPS == 16, "staging rows per pass");
     constexpr int XPASS = XP;
     const int xrows = BN + p.halo_lo + p.halo_hi;
     int nst = 0;                                       // diagnostic (EV_BAL_STAMPS): up to 16 s_memrealtime stamps per workgroup
@@ -2093,8 +2097,9 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
             if (c0 != 0 && sk_claim_taken(p.sk, claim_prev, tid, skw)) continue;     // its owner computes it: skip
         }
         if (pend_pub) { sk_publish(p.sk, g, get_tag(), tid); pend_pub = false; }
-        const int2* tl = p.taplist + (size_t)mt * p.tl_stride;
-        const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mt] : p.ntaps);
+        const int mtl = p.mt_mul > 1 ? mt * p.mt_mul : mt;   // (the tap tables are per 128-channel tile)
+        const int2* tl = p.taplist + (size_t)mtl * p.tl_stride;
+        const int nact = __builtin_amdgcn_readfirstlane(p.nact_tab ? p.nact_tab[mtl] : p.ntaps);
         const int mt32 = (m0 + wm * (TM * 32)) >> 5;
         const unsigned wbase = (unsigned)(mt32 * KG16) * 2048u;
         auto a_off = [&](int tap_bytes, int kg16) -> unsigned { return (unsigned)tap_bytes + wbase + (unsigned)kg16 * 2048u; };
@@ -2196,19 +2201,22 @@ __global__ __launch_bounds__(256, 2) void conv_h16_bal_kernel(const ConvParams p
                     }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-                    float* hr = hred + 4 * ((ch - cA) & 1);    // (two sets: the set of chunk ch - 2 was read before that chunk's second barrier)
+                    float* hr = hred + NW * ((ch - cA) & 1);   // (two sets: the set of chunk ch - 2 was read before that chunk's second barrier)
                     if (lane == 0) hr[wave] = mx;
                     ev_lds_barrier();                      // maxima published; the previous chunk's MFMAs (or the previous segment's epilogue) are done with LDS
                     float cmx = fmaxf(fmaxf(hr[0], hr[1]), fmaxf(hr[2], hr[3]));
+                    if constexpr (NW == 8) cmx = fmaxf(cmx, fmaxf(fmaxf(hr[4], hr[5]), fmaxf(hr[6], hr[7])));
                     if (!evh_is_finite(cmx)) {             // an Inf among the chunk's rows (workgroup-uniform, never on clean data): the finite maximum sets the scale
                         mx = mxf;
 #pragma unroll
                         for (int q = 0; q < XK; ++q) mx = (q * RPS + srow < xrows) ? fmaxf(mx, evh_absmax4_finite(xg[q])) : mx;
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-                        if (lane == 0) hred[8 + wave] = mx;    // (a third set: only this path writes it, always behind the barrier above)
+                        float* h3 = hred + 2 * NW;              // (a third set: only this path writes it, always behind the barrier above)
+                        if (lane == 0) h3[wave] = mx;
                         ev_lds_barrier();
-                        cmx = fmaxf(fmaxf(hred[8], hred[9]), fmaxf(hred[10], hred[11]));
+                        cmx = fmaxf(fmaxf(h3[0], h3[1]), fmaxf(h3[2], h3[3]));
+                        if constexpr (NW == 8) cmx = fmaxf(cmx, fmaxf(fmaxf(h3[4], h3[5]), fmaxf(h3[6], h3[7])));
                     }
                     const float xn = evh_scale_for(cmx);
                     if (xn != xs) {                        // (workgroup-uniform)

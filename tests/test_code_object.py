@@ -22,7 +22,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CONFIG2_LAUNCH_LIST = [
     r"conv_h16_kernel<128, 128, 2, 2, 1, 1>", r"conv_h16_kernel<128, 128, 2, 2, 3, 1>", r"conv_h16_kernel<64, 128, 2, 2, 1, 1>",
     r"conv_h16_kernel<128, 128, 2, 2, 1, 0>", r"conv_h16_kernel<128, 128, 2, 2, 3, 0>", r"conv_h16_kernel<64, 128, 2, 2, 1, 0>",
-    r"ln_mlp_h16_kernel<0>", r"ln_qkv_h16_kernel<0>", r"conv_h16_bal_kernel<128, 128, 2, 2, 1, 9, 9>",
+    r"ln_mlp_h16_kernel<0>", r"ln_qkv_h16_kernel<0>", r"conv_h16_bal_kernel<128, 128, 2, 2, 1, 9, 9>", r"conv_h16_bal_kernel<256, 128, 4, 2, 1, 5, 5>", r"conv_h16_bal_kernel<256, 128, 4, 2, 1, 6, 6>",
     r"resblock_pair_h16q_kernel<2, 2, 1>", r"resblock_pair_h16q_kernel<1, 4, 1>", r"resblock_pair_h16q_kernel<4, 1, 1>",
     r"resblock_pair_h16q_kernel<2, 2, 3>", r"resblock_pair_h16q_kernel<1, 4, 3>",
     r"resblock_pair_h16_kernel<2, 2, 1>", r"resblock_pair_h16_kernel<1, 4, 1>", r"resblock_pair_h16_kernel<4, 1, 1>",
